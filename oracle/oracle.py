@@ -1,0 +1,328 @@
+"""ctypes/numpy front end of the CPU oracle (oracle/rgbdslam_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  PARITY UNPINNED: the reference has no golden vectors and cannot be built here;
+see rgbdslam_oracle.h.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "librgbdslam_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_det6.restype = C.c_float
+        _LIB.orc_slam_create.restype = C.c_void_p
+        _LIB.orc_slam_buffer.restype = C.c_void_p
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("lvl", C.c_int), ("max_iter", C.c_int * 3), ("distThres", C.c_float),
+                ("angleThres", C.c_float), ("thres_cvg_alpha", C.c_float), ("thres_cvg_tr", C.c_float)]
+
+
+def icp_params(dist=0.05, angle=float(np.sin(np.deg2rad(20.0))), lvl=3):
+    p = IcpParams()
+    p.lvl = lvl
+    p.max_iter[0], p.max_iter[1], p.max_iter[2] = 3, 2, 1
+    p.distThres, p.angleThres = dist, angle
+    p.thres_cvg_alpha = p.thres_cvg_tr = 1e-6
+    return p
+
+
+# ---- stage 1 ---------------------------------------------------------------------------------
+def vertex_map_kinect(depth, calib):
+    n, m = depth.shape
+    depth = np.ascontiguousarray(depth, np.uint16)
+    out = np.empty((n, m, 3), np.float32)
+    lib().orc_vertex_map_kinect(_p(out), _p(depth), C.c_size_t(m), _p(_f32(calib)), n, m)
+    return out
+
+
+def cpy_char3(bgr):
+    n, m, _ = bgr.shape
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty((n, m, 3), np.float32)
+    lib().orc_cpy_char3(_p(bgr), C.c_size_t(3 * m), _p(out), n, m)
+    return out
+
+
+def compute_normal(vmap, inverse=True):
+    n, m, _ = vmap.shape
+    out = np.empty((n, m, 3), np.float32)
+    lib().orc_compute_normal(_p(out), _p(_f32(vmap)), n, m, int(inverse))
+    return out
+
+
+def intensity_sobel(rgb):
+    n, m, _ = rgb.shape
+    img = np.empty((n, m), np.float32)
+    gx = np.empty((n, m), np.float32)
+    gy = np.empty((n, m), np.float32)
+    lib().orc_intensity(_p(img), _p(_f32(rgb)), n, m)
+    lib().orc_sobel(_p(img), _p(gx), _p(gy), n, m)
+    return img, gx, gy
+
+
+# ---- stage 2/3 ------------------------------------------------------------------------------
+def icp_grid(n, m, fact):
+    gr, gc = C.c_int(), C.c_int()
+    lib().orc_icp_grid(n, m, fact, C.byref(gr), C.byref(gc))
+    return gr.value, gc.value
+
+
+def icp_match(intr, R, t, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, dist, angle, fact, want_corr=True):
+    n, m, _ = vmap.shape
+    gr, gc = icp_grid(n, m, fact)
+    buf = np.zeros((27, gr * gc), np.float32)
+    corr = np.empty((n, m), np.int32) if want_corr else None
+    lib().orc_icp_match(_p(_f32(intr)), _p(_f32(R)), _p(_f32(t)), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(rgb)),
+                        _p(_f32(gx)), _p(_f32(gy)), _p(_f32(vprev)), _p(_f32(nprev)), _p(_f32(rgbd_prev)),
+                        C.c_float(dist), C.c_float(angle), n, m, fact, _p(buf), _p(corr))
+    return buf, corr
+
+
+def icp_reduce(buf):
+    out = np.empty(27, np.float32)
+    lib().orc_icp_reduce(_p(_f32(buf)), buf.shape[1], _p(out))
+    return out
+
+
+def estimate_system(intr, R, t, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, dist, angle, fact):
+    n, m, _ = vmap.shape
+    A = np.empty((6, 6), np.float32)
+    b = np.empty(6, np.float32)
+    s = np.empty(27, np.float32)
+    lib().orc_estimate_system(_p(_f32(intr)), _p(_f32(R)), _p(_f32(t)), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(rgb)),
+                              _p(_f32(gx)), _p(_f32(gy)), _p(_f32(vprev)), _p(_f32(nprev)), _p(_f32(rgbd_prev)),
+                              C.c_float(dist), C.c_float(angle), n, m, fact, _p(A), _p(b), _p(s))
+    return A, b, s
+
+
+def det6(A):
+    return float(lib().orc_det6(_p(_f32(A))))
+
+
+def llt_solve6(A, b):
+    x = np.empty(6, np.float32)
+    rc = lib().orc_llt_solve6(_p(_f32(A)), _p(_f32(b)), _p(x))
+    return rc, x
+
+
+def inverse3(R_cm):
+    o = np.empty(9, np.float32)
+    lib().orc_inverse3(_p(_f32(R_cm)), _p(o))
+    return o
+
+
+def align_gauss_newton(prm, intr, vmap, nmap, rgb, vprev, nprev, rgbd_prev, poseR, poset, poseRPrev, posetPrev):
+    """Returns (ok, poseR(9, col-major), poset(3), trace[iters,33])."""
+    n, m, _ = vmap.shape
+    R = _f32(poseR).copy()
+    t = _f32(poset).copy()
+    trace = np.zeros((16, 33), np.float32)
+    nit = C.c_int()
+    ok = lib().orc_align_gauss_newton(C.byref(prm), _p(_f32(intr)), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(rgb)),
+                                      _p(_f32(vprev)), _p(_f32(nprev)), _p(_f32(rgbd_prev)), n, m, _p(R), _p(t),
+                                      _p(_f32(poseRPrev)), _p(_f32(posetPrev)), _p(trace), C.byref(nit))
+    return bool(ok), R, t, trace[:nit.value]
+
+
+# ---- stage 4 ----------------------------------------------------------------------------------
+def merge_depth_off(rgbd, depth, rgb, mask, calib):
+    n, m = depth.shape
+    rgbd = _f32(rgbd).copy()
+    mask = np.ascontiguousarray(mask, np.uint8).copy()
+    depth = np.ascontiguousarray(depth, np.uint16)
+    lib().orc_merge_depth_off(_p(rgbd), _p(depth), C.c_size_t(m), _p(_f32(rgb)), _p(mask), _p(_f32(calib)), n, m)
+    return rgbd, mask
+
+
+def vertex_map_gl(rgbd, calib):
+    n, m, _ = rgbd.shape
+    out = np.empty((n, m, 3), np.float32)
+    lib().orc_vertex_map_gl(_p(out), _p(_f32(rgbd)), _p(_f32(calib)), n, m)
+    return out
+
+
+def _ptr_table(arrs):
+    tab = (C.c_void_p * len(arrs))()
+    for k, a in enumerate(arrs):
+        tab[k] = a.ctypes.data
+    return tab
+
+
+def update(bumps, rgbs, masks, params, claims, stamp, vmap, rgbd, mask, label, pose, plane_lo=0, plane_hi=None):
+    """In-place on the lists of per-plane numpy arrays."""
+    n, m, _ = vmap.shape
+    N_prim, M_prim = masks[0].shape
+    if plane_hi is None:
+        plane_hi = len(masks)
+    lib().orc_update(_ptr_table(bumps), _ptr_table(rgbs), _ptr_table(masks), _ptr_table(params), _ptr_table(claims),
+                     C.c_uint32(stamp), _p(_f32(vmap)), _p(_f32(rgbd)), _p(np.ascontiguousarray(mask, np.uint8)),
+                     _p(np.ascontiguousarray(label, np.uint8)), _p(_f32(pose)), N_prim, M_prim, n, m,
+                     plane_lo, plane_hi)
+
+
+def vertex_from_bump(bump, rgb_bump, mask, param, lvl=1):
+    n, m = mask.shape
+    no, mo = n // lvl, m // lvl
+    v = np.empty((no, mo, 3), np.float32)
+    c = np.empty((no, mo, 4), np.float32)
+    mk = np.empty((no, mo, 4), np.float32)
+    lib().orc_vertex_from_bump(_p(v), _p(c), _p(mk), _p(np.ascontiguousarray(bump, np.uint16)),
+                               _p(np.ascontiguousarray(rgb_bump, np.uint8)), _p(np.ascontiguousarray(mask, np.uint8)),
+                               _p(_f32(param)), n, m, lvl)
+    return v, c, mk
+
+
+# ---- stage 5 ----------------------------------------------------------------------------------
+def transform_vertex_map(pose, vmap, rgbd):
+    n, m, _ = vmap.shape
+    v = _f32(vmap).copy()
+    r = _f32(rgbd).copy()
+    lib().orc_transform_vertex_map(_p(_f32(pose)), _p(v), _p(r), n, m)
+    return v, r
+
+
+def quad_trim_frame(vmap, thresh=0.1):
+    n, m, _ = vmap.shape
+    idx = np.empty(((n - 1) * (m - 1), 4), np.uint32)
+    lib().orc_quad_trim_frame(_p(idx), _p(_f32(vmap)), n, m, C.c_float(thresh))
+    return idx
+
+
+def raster(vmap, rgbd, calib, index=None, thresh=0.1, znear=0.5, zfar=10.0):
+    n, m, _ = vmap.shape
+    tex = np.empty((n, m, 4), np.float32)
+    zbuf = np.empty((n, m), np.uint64)
+    if index is not None:
+        index = np.ascontiguousarray(index, np.uint32)
+    lib().orc_raster(_p(tex), _p(zbuf), _p(_f32(vmap)), _p(_f32(rgbd)), _p(index), C.c_float(thresh),
+                     _p(_f32(calib)), C.c_float(znear), C.c_float(zfar), n, m)
+    return tex, zbuf
+
+
+def read_frame(tex, calib):
+    n, m, _ = tex.shape
+    v = np.empty((n, m, 3), np.float32)
+    r = np.empty((n, m, 4), np.float32)
+    lib().orc_read_frame(_p(v), _p(r), _p(_f32(tex)), _p(_f32(calib)), n, m)
+    return v, r
+
+
+def project_mask(pose, calib, mask, vmap):
+    n, m, _ = vmap.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_project_mask(_p(_f32(pose)), _p(_f32(calib)), _p(np.ascontiguousarray(mask, np.uint8)), _p(out),
+                           _p(_f32(vmap)), n, m)
+    return out
+
+
+def segment(label, vmap, nmap, pose, equations, eps=0.1, alpha=0.9):
+    n, m, _ = vmap.shape
+    lab = np.ascontiguousarray(label, np.uint8).copy()
+    swap = np.empty_like(lab)
+    eq = _f32(equations)
+    lib().orc_segment(_p(lab), _p(swap), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _p(eq),
+                      eq.size // 10, C.c_float(eps), C.c_float(alpha), n, m)
+    return lab
+
+
+def add_zbuff_off(depth, rgb, calib):
+    n, m = depth.shape
+    out = np.empty((n, m, 4), np.float32)
+    lib().orc_add_zbuff_off(_p(np.ascontiguousarray(depth, np.uint16)), C.c_size_t(m), _p(_f32(rgb)), _p(out),
+                            _p(_f32(calib)), n, m)
+    return out
+
+
+def init_mask(rgbd):
+    n, m, _ = rgbd.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_init_mask(_p(out), _p(_f32(rgbd)), n, m)
+    return out
+
+
+def seed_labels(vmap, nmap, pose, equations, eps=0.1, alpha=0.8):
+    n, m, _ = vmap.shape
+    out = np.empty((n, m), np.uint8)
+    eq = _f32(equations)
+    lib().orc_seed_labels(_p(out), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _p(eq), eq.size // 10,
+                          C.c_float(eps), C.c_float(alpha), n, m)
+    return out
+
+
+# ---- whole loop -------------------------------------------------------------------------------
+class Slam:
+    """CPU restatement of the display() loop (D1/GP-demo.cpp:138-296)."""
+
+    def __init__(self, n, m, calib, prm=None, max_planes=50, N_prim=1024, M_prim=1024, znear=0.5, zfar=10.0):
+        self.n, self.m, self.N_prim, self.M_prim = n, m, N_prim, M_prim
+        self.prm = prm or icp_params()
+        self._h = C.c_void_p(lib().orc_slam_create(n, m, _p(_f32(calib)), C.byref(self.prm), max_planes, N_prim,
+                                                   M_prim, C.c_float(znear), C.c_float(zfar)))
+
+    def close(self):
+        if self._h:
+            lib().orc_slam_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_planes(self, equations, centers):
+        eq = _f32(equations)
+        lib().orc_slam_set_planes(self._h, _p(eq), _p(_f32(centers)), eq.size // 10)
+
+    def step(self, depth, bgr):
+        return lib().orc_slam_step(self._h, _p(np.ascontiguousarray(depth, np.uint16)),
+                                   _p(np.ascontiguousarray(bgr, np.uint8)))
+
+    def pose(self):
+        R = np.empty(9, np.float32)
+        t = np.empty(3, np.float32)
+        lib().orc_slam_get_pose(self._h, _p(R), _p(t))
+        return R, t
+
+    def buffer(self, name):
+        nb = C.c_size_t()
+        ptr = lib().orc_slam_buffer(self._h, name.encode(), C.byref(nb))
+        if not ptr:
+            raise KeyError(name)
+        raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nb.value,)).copy()
+        P, Cc = self.n * self.m, self.N_prim * self.M_prim
+        if name in ("VMap", "NMap", "frame.VMap", "frame.NMap", "frame.RGB"):
+            return raw.view(np.float32).reshape(self.n, self.m, 3)
+        if name == "RGBD":
+            return raw.view(np.float32).reshape(self.n, self.m, 4)
+        if name in ("Mask", "Label"):
+            return raw.reshape(self.n, self.m)
+        if name.startswith("Bump"):
+            return raw.view(np.uint16).reshape(self.N_prim, self.M_prim, 3)
+        if name.startswith("RGBb"):
+            return raw.reshape(self.N_prim, self.M_prim, 3)
+        return raw.reshape(self.N_prim, self.M_prim)
