@@ -1,0 +1,179 @@
+/*
+ * rgbdslam.h -- C ABI of librgbdslam_hip.so: the MI355X (gfx950) implementation of the
+ * tracking-and-fusion hot path of diegothomas/RGB-D-SLAM (DemoStep1).
+ *
+ * Every entry point replaces one free host function that the reference declares in its four
+ * operator headers (Kernel.cuh, ICP.cuh, Primitive.cuh, RG.cuh) and that its L3/L4 classes call
+ * with raw device pointers; the reference declaration is cited per function
+ * (paths relative to DemoStep1/DemoStep1/).  Differences from the reference signatures:
+ *   - the file-scope globals (calib_dev, pose_dev, buf_dev, outbuf_dev ...) live in an opaque
+ *     rgbdslam_ctx, one per GPU;
+ *   - cv::gpu::DevMem2D_<T> arguments become (pointer, row pitch in bytes);
+ *   - functions return int: 0 = ok, < 0 = -(hipError_t), > 0 = RGBDSLAM_E_* argument errors;
+ *     nothing aborts the process (the reference's checkCudaErrors exits);
+ *   - work is enqueued on the context's stream and is asynchronous unless stated; call
+ *     rgbdslam_synchronize() (the reference ends every wrapper with cudaDeviceSynchronize()).
+ *
+ * Layout conventions: n = rows, m = cols, images row-major idx = i*m + j; VMap/NMap f32x3;
+ * RGB f32x3; RGBD f32x4 (.w = depth/100); Mask/Label u8; 4x4 poses column-major;
+ * 3x3 rotations column-major (Eigen), all exactly as in the reference.
+ */
+#ifndef RGBDSLAM_H
+#define RGBDSLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBDSLAM_OK 0
+#define RGBDSLAM_E_ARG 1      /* null pointer / non-positive size / unsupported value */
+#define RGBDSLAM_E_STATE 2    /* call order (e.g. buffers not allocated) */
+#define RGBDSLAM_E_LIMIT 3    /* size beyond a documented maximum */
+
+typedef struct rgbdslam_ctx rgbdslam_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Creates the per-GPU context on `device`; stream = hipStream_t (NULL = the null stream). */
+int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream);
+int rgbdslam_destroy(rgbdslam_ctx *ctx);
+int rgbdslam_set_stream(rgbdslam_ctx *ctx, void *stream);
+int rgbdslam_synchronize(rgbdslam_ctx *ctx);
+const char *rgbdslam_version(void);
+
+/* Kernel.cuh:7-8   void SetCalibrationMatrix(float *Calib_CPU); FreeCalibrationMatrix()
+ * calib = {fx, fy, cx, cy, k1..k5 (unused), ds, factor} (GP-demo.cpp:17,404). */
+int rgbdslam_set_calibration_matrix(rgbdslam_ctx *ctx, const float *calib11);
+/* Kernel.cuh:9-11  AllocPoseMatrix / SetPoseMatrix(float *pose_CPU) / FreePoseMatrix
+ * 16 floats, column-major; used by transform_vertex_map and project_mask. */
+int rgbdslam_set_pose_matrix(rgbdslam_ctx *ctx, const float *pose16);
+
+/* ---- stage 1: preprocessing --------------------------------------------------------------- */
+/* Kernel.cuh:14  void VertexMapKinect(float *VMap, DevMem2D_<unsigned short> depth, int n, int m) */
+int rgbdslam_vertex_map_kinect(rgbdslam_ctx *ctx, float *VMap, const uint16_t *depth,
+                               size_t depth_pitch_bytes, int n, int m);
+/* Kernel.cuh:32  void gpu_cpy_char3(DevMem2D_<uchar[3]> mat, float *rgb, int n, int m) */
+int rgbdslam_gpu_cpy_char3(rgbdslam_ctx *ctx, const uint8_t *bgr, size_t bgr_pitch_bytes,
+                           float *rgb, int n, int m);
+/* Kernel.cuh:17  void ComputeNormal(float *NMap, float *VMap, int n, int m, bool inverse) */
+int rgbdslam_compute_normal(rgbdslam_ctx *ctx, float *NMap, const float *VMap, int n, int m,
+                            int inverse);
+/* Kernel.cuh:28  void gpu_cpy(DevMem2D_<float> mat, float *rgb, int n, int m)  followed by the two
+ * cv::gpu::Sobel calls of RG.cpp:809-810, fused.  img may be NULL.  Pitches in bytes. */
+int rgbdslam_intensity_sobel(rgbdslam_ctx *ctx, const float *rgb, float *img, size_t img_pitch,
+                             float *gx, size_t gx_pitch, float *gy, size_t gy_pitch, int n, int m);
+
+/* ---- stage 2+3: ICP normal equations ------------------------------------------------------ */
+/* ICP.cuh:6-7  void AllocBuffers(int n, int m); void FreeBuffers()  (n, m = 8x8-block grid) */
+int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid_cols);
+int rgbdslam_free_buffers(rgbdslam_ctx *ctx);
+/* ICP.cuh:9-12  void EstimateSystemGaussNewton(float *Rcurr_dev, float *tcurr_dev, float *VMap,
+ *   float *NMap, float *RGB, DevMem2D_<float> Gx, DevMem2D_<float> Gy, float *VMap_prev,
+ *   float *NMap_prev, float *RGB_prev, float *intr, float distThres, float angleThres,
+ *   int n_row, int m_col, float *A, float *b, int fact)
+ * Rcurr_dev(9) tcurr_dev(3) intr(4) are DEVICE pointers; A(36, row-major) b(6) HOST outputs.
+ * BLOCKING (like the reference's cudaMemcpy D2H).  The 27 sums are accumulated in exactly the
+ * reference's order (8x8-block tree, then 512-strided chains + tree) and are therefore
+ * bit-identical to the oracle's.  corr_dev (optional, may be NULL): int32[n*m] debug map,
+ * -1 or the matched current-frame pixel index, indexed by model pixel. */
+int rgbdslam_estimate_system_gauss_newton(rgbdslam_ctx *ctx, const float *Rcurr_dev,
+                                          const float *tcurr_dev, const float *VMap,
+                                          const float *NMap, const float *RGB,
+                                          const float *Gx, size_t gx_pitch,
+                                          const float *Gy, size_t gy_pitch,
+                                          const float *VMap_prev, const float *NMap_prev,
+                                          const float *RGB_prev, const float *intr_dev,
+                                          float distThres, float angleThres, int n_row, int m_col,
+                                          float *A, float *b, int fact, int32_t *corr_dev);
+
+/* RG.cpp:797-932  bool RG::AlignFrameGaussNewton -- the whole coarse-to-fine Gauss-Newton loop
+ * resident on the device (match + reduce + 6x6 solve + pose update per iteration, no host round
+ * trips).  pose_state_dev = f32[24] device memory: poseR(9, col-major) poset(3) poseRPrev(9)
+ * posetPrev(3); poseR/poset are updated in place on success.  status_dev = int32[4] device
+ * memory: [0] 1 tracked / 0 lost, [1] iterations executed, [2..3] reserved.  Asynchronous. */
+typedef struct rgbdslam_icp_params {
+    int   lvl;                 /* 3 */
+    int   max_iter[3];         /* {3,2,1}  RG.h:124-126 */
+    float distThres, angleThres;
+    float thres_cvg_alpha, thres_cvg_tr;   /* 1e-6  RG.h:111 */
+} rgbdslam_icp_params;
+int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm,
+                                const float *VMap, const float *NMap, const float *RGB,
+                                const float *Gx, size_t gx_pitch, const float *Gy, size_t gy_pitch,
+                                const float *VMap_prev, const float *NMap_prev,
+                                const float *RGB_prev, int n_row, int m_col,
+                                float *pose_state_dev, int32_t *status_dev, float *trace_dev);
+
+/* ---- stage 4: fusion ---------------------------------------------------------------------- */
+/* Kernel.cuh:21  void MergeDepthOff(float *RGB_predicted, DevMem2D_<unsigned short> depth,
+ *                                   float *RGB, unsigned char *mask, int n, int m) */
+int rgbdslam_merge_depth_off(rgbdslam_ctx *ctx, float *RGBD_predicted, const uint16_t *depth,
+                             size_t depth_pitch_bytes, const float *RGB, uint8_t *mask,
+                             int n, int m);
+/* Kernel.cuh:15  void VertexMapGL(float *VMap, float *RGB, int n, int m) */
+int rgbdslam_vertex_map_gl(rgbdslam_ctx *ctx, float *VMap, const float *RGBD, int n, int m);
+/* Primitive.cuh:23-24  void Update_cu(unsigned short **BumpTab, unsigned char **RGBTab,
+ *   unsigned char **MaskTab, float **ParamTab, float *VMap, float *RGB, unsigned char *Mask,
+ *   unsigned char *Label, float *pose, int N_prim, int M_prim, int n, int m)
+ * Tables are DEVICE arrays of DEVICE pointers; pose is a HOST pointer (16 floats).
+ * ClaimTab (device array of device u64 pointers, one N_prim*M_prim slab per plane, zeroed once)
+ * and stamp (strictly increasing per call, > 0) implement the deterministic winner rule that
+ * replaces the reference's data race.  Only labels in [plane_lo, plane_hi) are
+ * processed (plane-partitioned multi-GPU); pass 0, INT_MAX for all. */
+int rgbdslam_update(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab,
+                    float **ParamTab, uint64_t **ClaimTab, uint32_t stamp,
+                    const float *VMap, const float *RGBD, const uint8_t *Mask,
+                    const uint8_t *Label, const float *pose16_host, int N_prim, int M_prim,
+                    int n, int m, int plane_lo, int plane_hi);
+/* Primitive.cuh:16  void VertexFromBump(float *VMap_VBO, float *RGB_VBO, float *Mask_VBO,
+ *   unsigned short *Bump_dev, unsigned char *RGB_bump_dev, unsigned char *Mask_dev,
+ *   float *param_dev, int n, int m, int lvl) */
+int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *RGBA, float *MaskOut,
+                              const uint16_t *Bump, const uint8_t *RGB_bump, const uint8_t *Mask,
+                              const float *param_dev, int n, int m, int lvl);
+
+/* ---- stage 5: prediction ------------------------------------------------------------------ */
+/* Kernel.cuh:19  void TransformVertexMap(float *VMap, float *RGBD, int n, int m)  (uses pose) */
+int rgbdslam_transform_vertex_map(rgbdslam_ctx *ctx, float *VMap, float *RGBD, int n, int m);
+/* Kernel.cuh:20  void QuadTrimFrame(float *VMap, unsigned int *indices_dev, int n, int m, float thresh) */
+int rgbdslam_quad_trim_frame(rgbdslam_ctx *ctx, const float *VMap, uint32_t *indices, int n, int m,
+                             float thresh);
+/* Replaces the OpenGL pass DisplayPredictedFBO (GP-demo.cpp:98-113) + PredictedFrame::Draw(true,
+ * true) (Frame.cpp:247-279): z-buffered rasterisation of the quad mesh into tex = f32x4[n*m]
+ * (r, g, b, depth/100; 0 = nothing drawn).  indices may be NULL: quads are then trimmed inline
+ * with `thresh` exactly as quad_trim_frame would.  zbuf = u64[n*m] scratch that must hold
+ * 0xFF..FF on entry (rgbdslam_raster_clear) and holds it again on return. */
+int rgbdslam_raster_clear(rgbdslam_ctx *ctx, uint64_t *zbuf, int n, int m);
+int rgbdslam_predict_raster(rgbdslam_ctx *ctx, float *tex, uint64_t *zbuf, const float *VMap,
+                            const float *RGBD, const uint32_t *indices, float thresh,
+                            float znear, float zfar, int n, int m);
+/* Kernel.cuh:18  void ReadFrame_cu(float *Vmap, float *RGBD, float *NMap, cudaArray *Array, int n, int m)
+ * The GL texture becomes the plain f32x4 buffer written by rgbdslam_predict_raster. */
+int rgbdslam_read_frame(rgbdslam_ctx *ctx, float *VMap, float *RGBD, const float *tex, int n, int m);
+/* Kernel.cuh:24  void ProjectMask_cu(unsigned char *mask, unsigned char *mask_swap, float *VMap, int n, int m) */
+int rgbdslam_project_mask(rgbdslam_ctx *ctx, const uint8_t *mask, uint8_t *mask_swap,
+                          const float *VMap, int n, int m);
+/* RG.cuh:11  void Segment_cu(unsigned char *Label, float *VMap, float *NMap, float *pose,
+ *   float *Equations, int nbPlans, float epsilon, float alpha, int n, int m)
+ * pose = HOST pointer; Equations = DEVICE pointer.  Label_swap = u8[n*m] scratch: the three
+ * passes are double-buffered; the result is left in Label. */
+int rgbdslam_segment(rgbdslam_ctx *ctx, uint8_t *Label, uint8_t *Label_swap, const float *VMap,
+                     const float *NMap, const float *pose16_host, const float *Equations_dev,
+                     int nbPlans, float epsilon, float alpha, int n, int m);
+/* Kernel.cuh:35  void gpu_add_zbuffOff(DevMem2D_<unsigned short> depth, float *rgb_in, float *rgb, int n, int m) */
+int rgbdslam_gpu_add_zbuff_off(rgbdslam_ctx *ctx, const uint16_t *depth, size_t depth_pitch_bytes,
+                               const float *rgb_in, float *RGBD, int n, int m);
+/* Kernel.cuh:23  void InitMask_cu(unsigned char *mask, float *RGB, int n, int m) */
+int rgbdslam_init_mask(rgbdslam_ctx *ctx, uint8_t *mask, const float *RGBD, int n, int m);
+/* Test-harness stand-in for plane detection (not in the reference): labels by
+ * plane membership.  pose = HOST pointer. */
+int rgbdslam_seed_labels(rgbdslam_ctx *ctx, uint8_t *Label, const float *VMap, const float *NMap,
+                         const float *pose16_host, const float *Equations_dev, int nbPlans,
+                         float epsilon, float alpha, int n, int m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

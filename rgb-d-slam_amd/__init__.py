@@ -1,0 +1,189 @@
+"""rgb-d-slam_amd -- MI355X-native tracking-and-fusion hot path of diegothomas/RGB-D-SLAM.
+
+The product is librgbdslam_hip.so (hand-written HIP for gfx950 behind the C ABI of
+include/rgbdslam.h) plus the C++ host mirror of the reference's L3/L4 classes
+(librgbdslam_host.so).  This module is only the ctypes binding used by tests and bench.py;
+PyTorch supplies device memory and streams, nothing else.  There is NO CPU fallback: a missing
+library raises at load time.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgbdslam_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "librgbdslam_host.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rgbdslam.h")
+
+_lib = None
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("lvl", C.c_int), ("max_iter", C.c_int * 3), ("distThres", C.c_float),
+                ("angleThres", C.c_float), ("thres_cvg_alpha", C.c_float), ("thres_cvg_tr", C.c_float)]
+
+
+def icp_params(dist=0.05, angle=0.3420201433256687, lvl=3):
+    """TUM fr1/xyz settings (D1/GP-demo.cpp:409, D1/RG.h:111-126)."""
+    p = IcpParams()
+    p.lvl = lvl
+    p.max_iter[0], p.max_iter[1], p.max_iter[2] = 3, 2, 1
+    p.distThres, p.angleThres = dist, angle
+    p.thres_cvg_alpha = p.thres_cvg_tr = 1e-6
+    return p
+
+
+def load():
+    """Loads the HIP library or raises -- the product path never falls back to CPU code."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("librgbdslam_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rgbdslam_version.restype = C.c_char_p
+    return _lib
+
+
+class SlamError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise SlamError("%s failed with code %d" % (what, rc))
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(int(t))
+
+
+def _host16(a):
+    arr = (C.c_float * len(a))(*[float(x) for x in a])
+    return arr
+
+
+class Context:
+    """Thin owner of a rgbdslam_ctx; arguments are torch CUDA tensors (or raw device addresses)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        self._h = C.c_void_p()
+        _chk(self.lib.rgbdslam_create(C.byref(self._h), int(device), C.c_void_p(stream or 0)), "rgbdslam_create")
+
+    def close(self):
+        if self._h:
+            self.lib.rgbdslam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- context --
+    def set_stream(self, stream):
+        _chk(self.lib.rgbdslam_set_stream(self._h, C.c_void_p(stream or 0)), "set_stream")
+
+    def synchronize(self):
+        _chk(self.lib.rgbdslam_synchronize(self._h), "synchronize")
+
+    def set_calibration_matrix(self, calib):
+        _chk(self.lib.rgbdslam_set_calibration_matrix(self._h, _host16(calib)), "set_calibration_matrix")
+
+    def set_pose_matrix(self, pose):
+        _chk(self.lib.rgbdslam_set_pose_matrix(self._h, _host16(pose)), "set_pose_matrix")
+
+    # -- stage 1 --
+    def vertex_map_kinect(self, vmap, depth, pitch, n, m):
+        _chk(self.lib.rgbdslam_vertex_map_kinect(self._h, _ptr(vmap), _ptr(depth), C.c_size_t(pitch), n, m), "vertex_map_kinect")
+
+    def gpu_cpy_char3(self, bgr, pitch, rgb, n, m):
+        _chk(self.lib.rgbdslam_gpu_cpy_char3(self._h, _ptr(bgr), C.c_size_t(pitch), _ptr(rgb), n, m), "gpu_cpy_char3")
+
+    def compute_normal(self, nmap, vmap, n, m, inverse=True):
+        _chk(self.lib.rgbdslam_compute_normal(self._h, _ptr(nmap), _ptr(vmap), n, m, int(inverse)), "compute_normal")
+
+    def intensity_sobel(self, rgb, img, gx, gy, n, m, pitch=None):
+        pitch = pitch or 4 * m
+        _chk(self.lib.rgbdslam_intensity_sobel(self._h, _ptr(rgb), _ptr(img), C.c_size_t(pitch), _ptr(gx), C.c_size_t(pitch),
+                                               _ptr(gy), C.c_size_t(pitch), n, m), "intensity_sobel")
+
+    # -- stage 2/3 --
+    def alloc_buffers(self, grid_rows, grid_cols):
+        _chk(self.lib.rgbdslam_alloc_buffers(self._h, grid_rows, grid_cols), "alloc_buffers")
+
+    def estimate_system(self, R_dev, t_dev, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, intr_dev, dist, angle,
+                        n, m, fact, corr=None, pitch=None):
+        pitch = pitch or 4 * m
+        A = (C.c_float * 36)()
+        b = (C.c_float * 6)()
+        _chk(self.lib.rgbdslam_estimate_system_gauss_newton(
+            self._h, _ptr(R_dev), _ptr(t_dev), _ptr(vmap), _ptr(nmap), _ptr(rgb), _ptr(gx), C.c_size_t(pitch), _ptr(gy),
+            C.c_size_t(pitch), _ptr(vprev), _ptr(nprev), _ptr(rgbd_prev), _ptr(intr_dev), C.c_float(dist), C.c_float(angle),
+            n, m, A, b, fact, _ptr(corr)), "estimate_system_gauss_newton")
+        return list(A), list(b)
+
+    def align_gauss_newton(self, prm, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, n, m, pose_state, status,
+                           trace=None, pitch=None):
+        pitch = pitch or 4 * m
+        _chk(self.lib.rgbdslam_align_gauss_newton(
+            self._h, C.byref(prm), _ptr(vmap), _ptr(nmap), _ptr(rgb), _ptr(gx), C.c_size_t(pitch), _ptr(gy),
+            C.c_size_t(pitch), _ptr(vprev), _ptr(nprev), _ptr(rgbd_prev), n, m, _ptr(pose_state), _ptr(status),
+            _ptr(trace)), "align_gauss_newton")
+
+    # -- stage 4 --
+    def merge_depth_off(self, rgbd, depth, pitch, rgb, mask, n, m):
+        _chk(self.lib.rgbdslam_merge_depth_off(self._h, _ptr(rgbd), _ptr(depth), C.c_size_t(pitch), _ptr(rgb), _ptr(mask), n, m),
+             "merge_depth_off")
+
+    def vertex_map_gl(self, vmap, rgbd, n, m):
+        _chk(self.lib.rgbdslam_vertex_map_gl(self._h, _ptr(vmap), _ptr(rgbd), n, m), "vertex_map_gl")
+
+    def update(self, bump_tab, rgb_tab, mask_tab, param_tab, claim_tab, stamp, vmap, rgbd, mask, label, pose, N_prim,
+               M_prim, n, m, plane_lo=0, plane_hi=2 ** 31 - 1):
+        _chk(self.lib.rgbdslam_update(self._h, _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab), _ptr(param_tab), _ptr(claim_tab),
+                                      C.c_uint32(stamp), _ptr(vmap), _ptr(rgbd), _ptr(mask), _ptr(label), _host16(pose),
+                                      N_prim, M_prim, n, m, plane_lo, plane_hi), "update")
+
+    def vertex_from_bump(self, vmap, rgba, mask_out, bump, rgb_bump, mask, param, n, m, lvl=1):
+        _chk(self.lib.rgbdslam_vertex_from_bump(self._h, _ptr(vmap), _ptr(rgba), _ptr(mask_out), _ptr(bump), _ptr(rgb_bump),
+                                                _ptr(mask), _ptr(param), n, m, lvl), "vertex_from_bump")
+
+    # -- stage 5 --
+    def transform_vertex_map(self, vmap, rgbd, n, m):
+        _chk(self.lib.rgbdslam_transform_vertex_map(self._h, _ptr(vmap), _ptr(rgbd), n, m), "transform_vertex_map")
+
+    def quad_trim_frame(self, vmap, indices, n, m, thresh=0.1):
+        _chk(self.lib.rgbdslam_quad_trim_frame(self._h, _ptr(vmap), _ptr(indices), n, m, C.c_float(thresh)), "quad_trim_frame")
+
+    def raster_clear(self, zbuf, n, m):
+        _chk(self.lib.rgbdslam_raster_clear(self._h, _ptr(zbuf), n, m), "raster_clear")
+
+    def predict_raster(self, tex, zbuf, vmap, rgbd, indices, n, m, thresh=0.1, znear=0.5, zfar=10.0):
+        _chk(self.lib.rgbdslam_predict_raster(self._h, _ptr(tex), _ptr(zbuf), _ptr(vmap), _ptr(rgbd), _ptr(indices),
+                                              C.c_float(thresh), C.c_float(znear), C.c_float(zfar), n, m), "predict_raster")
+
+    def read_frame(self, vmap, rgbd, tex, n, m):
+        _chk(self.lib.rgbdslam_read_frame(self._h, _ptr(vmap), _ptr(rgbd), _ptr(tex), n, m), "read_frame")
+
+    def project_mask(self, mask, mask_swap, vmap, n, m):
+        _chk(self.lib.rgbdslam_project_mask(self._h, _ptr(mask), _ptr(mask_swap), _ptr(vmap), n, m), "project_mask")
+
+    def segment(self, label, label_swap, vmap, nmap, pose, equations, nb, n, m, eps=0.1, alpha=0.9):
+        _chk(self.lib.rgbdslam_segment(self._h, _ptr(label), _ptr(label_swap), _ptr(vmap), _ptr(nmap), _host16(pose),
+                                       _ptr(equations), nb, C.c_float(eps), C.c_float(alpha), n, m), "segment")
+
+    def gpu_add_zbuff_off(self, depth, pitch, rgb_in, rgbd, n, m):
+        _chk(self.lib.rgbdslam_gpu_add_zbuff_off(self._h, _ptr(depth), C.c_size_t(pitch), _ptr(rgb_in), _ptr(rgbd), n, m),
+             "gpu_add_zbuff_off")
+
+    def init_mask(self, mask, rgbd, n, m):
+        _chk(self.lib.rgbdslam_init_mask(self._h, _ptr(mask), _ptr(rgbd), n, m), "init_mask")
+
+    def seed_labels(self, label, vmap, nmap, pose, equations, nb, n, m, eps=0.1, alpha=0.8):
+        _chk(self.lib.rgbdslam_seed_labels(self._h, _ptr(label), _ptr(vmap), _ptr(nmap), _host16(pose), _ptr(equations), nb,
+                                           C.c_float(eps), C.c_float(alpha), n, m), "seed_labels")

@@ -1,0 +1,89 @@
+// common.hpp -- shared declarations of librgbdslam_hip.so (gfx950 only).
+// Arithmetic contract: IEEE round-to-nearest, no FMA contraction (-ffp-contract=off), correctly
+// rounded f32 divide/sqrt (hipcc default), C promotion rules of the reference's expressions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/rgbdslam.h"
+
+#define SLAM_MAX_DEPTH 100.0     // D1/cudaTypes.cuh:51
+#define SLAM_MAXTOLERANCE 0.2    // D1/cudaTypes.cuh:47
+
+// Launch geometry: one lane per COLUMN (coalesced rows), 64 x 4 threads per workgroup.
+#define TILE_W 64
+#define TILE_H 4
+
+struct CalibV { float v[11]; };
+struct PoseV  { float v[16]; };
+
+// Device-resident state of the Gauss-Newton loop (RG::AlignFrameGaussNewton, D1/RG.cpp:797-932).
+struct IcpState {
+    float Rinv[9], tinv[3];    // Rcurr_inv, tcurr_inv
+    float Rcurr[9], tcurr[3];  // the pair uploaded for the current iteration (RG.cpp:851-855)
+    float intr[4];
+    int   cvg, fail, iters, pad;
+};
+
+struct rgbdslam_ctx {
+    int device;
+    hipStream_t stream;
+    CalibV calib;
+    PoseV pose;
+    bool have_calib;
+    // ICP.cu:5-7 globals
+    float *buf_dev;      // f32[27][nblk]
+    size_t buf_blocks;   // capacity in 8x8 blocks
+    float *outbuf_dev;   // f32[27]
+    float *out_host;     // pinned f32[27]
+    IcpState *icp_state; // device
+};
+
+#define HIP_TRY(expr)                                     \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) return -(int)_e;            \
+    } while (0)
+
+static inline dim3 grid2d(int n, int m) { return dim3((m + TILE_W - 1) / TILE_W, (n + TILE_H - 1) / TILE_H); }
+static inline dim3 block2d() { return dim3(TILE_W, TILE_H); }
+
+// CUDA __float2int_rn / __float2int_rd semantics: saturating, NaN -> 0.
+__device__ __forceinline__ int f2i_rn(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)__builtin_rintf(x);
+}
+__device__ __forceinline__ int f2i_rd(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)__builtin_floorf(x);
+}
+
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const float *p, size_t idx) {
+    F3 r; r.x = p[3 * idx]; r.y = p[3 * idx + 1]; r.z = p[3 * idx + 2]; return r;
+}
+__device__ __forceinline__ void st3(float *p, size_t idx, float a, float b, float c) {
+    p[3 * idx] = a; p[3 * idx + 1] = b; p[3 * idx + 2] = c;
+}
+// column-major 4x4 applied to a point / a direction (left-to-right sums, D1/Kernel.cu:365-367)
+__device__ __forceinline__ F3 xf_point(const float *P, F3 a) {
+    F3 r;
+    r.x = ((P[0] * a.x + P[4] * a.y) + P[8] * a.z) + P[12];
+    r.y = ((P[1] * a.x + P[5] * a.y) + P[9] * a.z) + P[13];
+    r.z = ((P[2] * a.x + P[6] * a.y) + P[10] * a.z) + P[14];
+    return r;
+}
+__device__ __forceinline__ F3 xf_dir(const float *P, F3 a) {
+    F3 r;
+    r.x = (P[0] * a.x + P[4] * a.y) + P[8] * a.z;
+    r.y = (P[1] * a.x + P[5] * a.y) + P[9] * a.z;
+    r.z = (P[2] * a.x + P[6] * a.y) + P[10] * a.z;
+    return r;
+}
+__device__ __forceinline__ bool is_zero3(F3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }

@@ -1,0 +1,274 @@
+// preprocess.hip -- stage 1 (depth/colour -> vertex, normal, intensity-gradient maps) and the
+// per-pixel model maintenance kernels of stage 4/5 (merge, vertex-from-depth, model seeding).
+// Lanes run along image columns so every row segment is one coalesced burst.
+#include "common.hpp"
+
+// ---- D1/Kernel.cu:33-52 VertexMapKinectKernel ------------------------------------------------
+__global__ void k_vertex_map_kinect(float *__restrict__ VMap, const uint16_t *__restrict__ depth,
+                                    size_t pitch, CalibV c, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    const uint16_t *row = (const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * pitch);
+    uint16_t d = row[j];
+    if (d == 0) { st3(VMap, idx, 0.0f, 0.0f, 0.0f); return; }
+    float s = c.v[9] / c.v[10];
+    float fd = (float)d;
+    float sd = s * fd;
+    st3(VMap, idx, sd * (((float)j - c.v[2]) / c.v[0]), sd * (((float)i - c.v[3]) / c.v[1]), (-s) * fd);
+}
+
+// ---- D1/Kernel.cu:739-753 CpyKernelChar3 ------------------------------------------------------
+__global__ void k_cpy_char3(const uint8_t *__restrict__ bgr, size_t pitch, float *__restrict__ rgb, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    const uint8_t *px = bgr + (size_t)(n - i - 1) * pitch + 3 * (size_t)j;
+    st3(rgb, idx, (float)((double)(float)px[2] / 255.0), (float)((double)(float)px[1] / 255.0),
+        (float)((double)(float)px[0] / 255.0));
+}
+
+// ---- D1/Kernel.cu:123-307 NormalKernel --------------------------------------------------------
+// one of the four triangles around the pixel: normalised cross((a-p),(b-p)); returns 1 if counted
+__device__ __forceinline__ int tri_normal(F3 p, F3 a, F3 b, F3 &o) {
+    o.x = o.y = o.z = 0.0f;
+    if (a.z != 0.0f && b.z != 0.0f) {
+        float ax = a.x - p.x, ay = a.y - p.y, az = a.z - p.z;
+        float bx = b.x - p.x, by = b.y - p.y, bz = b.z - p.z;
+        float cx = ay * bz - az * by;
+        float cy = az * bx - ax * bz;
+        float cz = ax * by - ay * bx;
+        float nn = (cx * cx + cy * cy + cz * cz);
+        o.x = cx; o.y = cy; o.z = cz;
+        if (nn != 0.0f) {
+            float r = __builtin_sqrtf(nn);
+            o.x = cx / r; o.y = cy / r; o.z = cz / r;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void normal_at(float *__restrict__ NMap, const float *__restrict__ VMap,
+                                          int i, int j, int n, int m, int inverse) {
+    size_t idx = (size_t)i * m + j;
+    F3 p = ld3(VMap, idx);
+    if (i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f) { st3(NMap, idx, 0.0f, 0.0f, 0.0f); return; }
+    F3 dn = ld3(VMap, idx + m), up = ld3(VMap, idx - m), rt = ld3(VMap, idx + 1), lf = ld3(VMap, idx - 1);
+    F3 n1, n2, n3, n4;
+    int tot = tri_normal(p, dn, rt, n1);
+    tot += tri_normal(p, rt, up, n2);
+    tot += tri_normal(p, up, lf, n3);
+    tot += tri_normal(p, lf, dn, n4);
+    if (tot == 0) { st3(NMap, idx, 0.0f, 0.0f, 0.0f); return; }
+    float ft = (float)tot;
+    float a0 = (((n1.x + n2.x) + n3.x) + n4.x) / ft;
+    float a1 = (((n1.y + n2.y) + n3.y) + n4.y) / ft;
+    float a2 = (((n1.z + n2.z) + n3.z) + n4.z) / ft;
+    float nn = __builtin_sqrtf((a0 * a0 + a1 * a1) + a2 * a2);
+    if (nn != 0.0f) {
+        if (inverse) st3(NMap, idx, (-a0) / nn, (-a1) / nn, (-a2) / nn);
+        else st3(NMap, idx, a0 / nn, a1 / nn, a2 / nn);
+    } else {
+        st3(NMap, idx, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+__global__ void k_compute_normal(float *__restrict__ NMap, const float *__restrict__ VMap, int n, int m, int inverse) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    normal_at(NMap, VMap, i, j, n, m, inverse);
+}
+
+// ---- D1/Kernel.cu:670-682 CpyKernel + cv::gpu::Sobel x2 (D1/RG.cpp:807-810), fused -------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__global__ void k_intensity_sobel(const float *__restrict__ rgb, float *__restrict__ img, size_t img_pitch,
+                                  float *__restrict__ gx, size_t gx_pitch, float *__restrict__ gy,
+                                  size_t gy_pitch, int n, int m) {
+    // LDS tile of intensities with a one-pixel reflect-101 halo
+    __shared__ float tile[TILE_H + 2][TILE_W + 2];
+    int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    int tid = threadIdx.y * TILE_W + threadIdx.x;
+    for (int e = tid; e < (TILE_H + 2) * (TILE_W + 2); e += TILE_W * TILE_H) {
+        int r = e / (TILE_W + 2), c = e % (TILE_W + 2);
+        int ii = i0 + r - 1, jj = j0 + c - 1;
+        float v = 0.0f;
+        if (ii <= n && jj <= m) {   // one past the edge is still needed (reflected)
+            size_t s = (size_t)reflect101(ii, n) * m + reflect101(jj, m);
+            float sum = (rgb[3 * s + 2] + rgb[3 * s + 1]) + rgb[3 * s];   // Kernel.cu:678
+            v = (float)((double)sum / 3.0);
+        }
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
+    if (i >= n || j >= m) return;
+    int r = threadIdx.y + 1, c = threadIdx.x + 1;
+    float rowd[3], rows[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = tile[r - 1 + k][c - 1], b = tile[r - 1 + k][c], cc = tile[r - 1 + k][c + 1];
+        float s = 0.0f;
+        s = s + a * -1.0f; s = s + b * 0.0f; s = s + cc * 1.0f;
+        rowd[k] = s;
+        s = 0.0f;
+        s = s + a * 1.0f; s = s + b * 2.0f; s = s + cc * 1.0f;
+        rows[k] = s;
+    }
+    float s = 0.0f;
+    s = s + rowd[0] * 1.0f; s = s + rowd[1] * 2.0f; s = s + rowd[2] * 1.0f;
+    *(float *)((char *)gx + (size_t)i * gx_pitch + 4 * (size_t)j) = s;
+    s = 0.0f;
+    s = s + rows[0] * -1.0f; s = s + rows[1] * 0.0f; s = s + rows[2] * 1.0f;
+    *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
+    if (img) *(float *)((char *)img + (size_t)i * img_pitch + 4 * (size_t)j) = tile[r][c];
+}
+
+// ---- D1/Kernel.cu:440-526 MergeDepthOffKernel ---------------------------------------------------
+__global__ void k_merge_depth_off(float *__restrict__ RGBD, const uint16_t *__restrict__ depth, size_t pitch,
+                                  const float *__restrict__ RGB, uint8_t *__restrict__ mask, CalibV c, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    const uint16_t *row = (const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * pitch);
+    float ds = c.v[9], factor = c.v[10];
+    float dv = (ds / factor) * (float)row[j];
+    float4 px = *(float4 *)(RGBD + 4 * idx);
+    float dp = (float)((double)px.w * SLAM_MAX_DEPTH);
+    float mv = (float)((double)(float)mask[idx] - 10.0);
+    const float mt = 1.0f;
+    F3 col = ld3(RGB, idx);
+    px.x = col.x; px.y = col.y; px.z = col.z;
+    int newmask = -1;
+    if ((double)dv < 0.1) {
+    } else if ((double)dp < 0.1 || __builtin_fabs((double)mv + 9.0) < 0.01) {
+        px.w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
+    } else if ((double)dv < ((double)dp - SLAM_MAXTOLERANCE)) {
+        px.w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
+    } else {
+        double mx = 1.0 > 1.0 * (double)dv ? 1.0 : 1.0 * (double)dv;
+        if ((double)dv > ((double)dp + mx * SLAM_MAXTOLERANCE)) {
+            newmask = 10;
+        } else {
+            float am = __builtin_fabsf(mv);
+            float avg = (dv * mt + am * dp) / (mt + am);
+            px.w = (float)((double)avg / SLAM_MAX_DEPTH);
+            double mk = (double)(mt + am) + 10.0;
+            if (mk > 255.0) mk = 255.0;
+            newmask = (int)(uint8_t)mk;
+        }
+    }
+    *(float4 *)(RGBD + 4 * idx) = px;
+    if (newmask >= 0) mask[idx] = (uint8_t)newmask;
+}
+
+// ---- D1/Kernel.cu:54-72 VertexMapGLKernel -------------------------------------------------------
+__device__ __forceinline__ void vertex_from_w(float *__restrict__ VMap, size_t idx, float w, int i, int j, const CalibV &c) {
+    double z = (double)w * SLAM_MAX_DEPTH;
+    float x = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)j - c.v[2]) / c.v[0]));
+    float y = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)i - c.v[3]) / c.v[1]));
+    st3(VMap, idx, x, y, (float)((double)(-w) * SLAM_MAX_DEPTH));
+}
+__global__ void k_vertex_map_gl(float *__restrict__ VMap, const float *__restrict__ RGBD, CalibV c, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    vertex_from_w(VMap, idx, RGBD[4 * idx + 3], i, j, c);
+}
+
+// ---- D1/Kernel.cu:783-802 AddZBUFFOffKernel, 616-632 InitMaskKernel -----------------------------
+__global__ void k_add_zbuff_off(const uint16_t *__restrict__ depth, size_t pitch, const float *__restrict__ rgb_in,
+                                float *__restrict__ RGBD, CalibV c, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    const uint16_t *row = (const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * pitch);
+    float z = (c.v[9] / c.v[10]) * (float)row[j];
+    F3 col = ld3(rgb_in, idx);
+    float4 o;
+    o.x = col.x; o.y = col.y; o.z = col.z;
+    o.w = ((double)z > SLAM_MAX_DEPTH || (double)z < 0.0) ? 0.0f : (float)((double)z / SLAM_MAX_DEPTH);
+    *(float4 *)(RGBD + 4 * idx) = o;
+}
+__global__ void k_init_mask(uint8_t *__restrict__ mask, const float *__restrict__ RGBD, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    mask[idx] = (RGBD[4 * idx + 3] == 0.0f) ? 10 : 11;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+#define CHECK_CTX(ctx) do { if (!(ctx)) return RGBDSLAM_E_ARG; } while (0)
+#define CHECK_DIM(n, m) do { if ((n) <= 0 || (m) <= 0) return RGBDSLAM_E_ARG; } while (0)
+
+extern "C" int rgbdslam_vertex_map_kinect(rgbdslam_ctx *ctx, float *VMap, const uint16_t *depth, size_t pitch, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!VMap || !depth || pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    hipLaunchKernelGGL(k_vertex_map_kinect, grid2d(n, m), block2d(), 0, ctx->stream, VMap, depth, pitch, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_gpu_cpy_char3(rgbdslam_ctx *ctx, const uint8_t *bgr, size_t pitch, float *rgb, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!bgr || !rgb || pitch < 3 * (size_t)m) return RGBDSLAM_E_ARG;
+    hipLaunchKernelGGL(k_cpy_char3, grid2d(n, m), block2d(), 0, ctx->stream, bgr, pitch, rgb, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_compute_normal(rgbdslam_ctx *ctx, float *NMap, const float *VMap, int n, int m, int inverse) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!NMap || !VMap || NMap == VMap) return RGBDSLAM_E_ARG;
+    hipLaunchKernelGGL(k_compute_normal, grid2d(n, m), block2d(), 0, ctx->stream, NMap, VMap, n, m, inverse);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_intensity_sobel(rgbdslam_ctx *ctx, const float *rgb, float *img, size_t img_pitch, float *gx,
+                                        size_t gx_pitch, float *gy, size_t gy_pitch, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!rgb || !gx || !gy || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (img && img_pitch < 4 * (size_t)m) return RGBDSLAM_E_ARG;
+    hipLaunchKernelGGL(k_intensity_sobel, grid2d(n, m), block2d(), 0, ctx->stream, rgb, img, img_pitch, gx, gx_pitch, gy, gy_pitch, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_merge_depth_off(rgbdslam_ctx *ctx, float *RGBD, const uint16_t *depth, size_t pitch,
+                                        const float *RGB, uint8_t *mask, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!RGBD || !depth || !RGB || !mask || pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    hipLaunchKernelGGL(k_merge_depth_off, grid2d(n, m), block2d(), 0, ctx->stream, RGBD, depth, pitch, RGB, mask, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_vertex_map_gl(rgbdslam_ctx *ctx, float *VMap, const float *RGBD, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!VMap || !RGBD) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    hipLaunchKernelGGL(k_vertex_map_gl, grid2d(n, m), block2d(), 0, ctx->stream, VMap, RGBD, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_gpu_add_zbuff_off(rgbdslam_ctx *ctx, const uint16_t *depth, size_t pitch, const float *rgb_in,
+                                          float *RGBD, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!depth || !rgb_in || !RGBD || pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    hipLaunchKernelGGL(k_add_zbuff_off, grid2d(n, m), block2d(), 0, ctx->stream, depth, pitch, rgb_in, RGBD, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rgbdslam_init_mask(rgbdslam_ctx *ctx, uint8_t *mask, const float *RGBD, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!mask || !RGBD) return RGBDSLAM_E_ARG;
+    hipLaunchKernelGGL(k_init_mask, grid2d(n, m), block2d(), 0, ctx->stream, mask, RGBD, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

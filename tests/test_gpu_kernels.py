@@ -1,0 +1,383 @@
+"""GPU parity: every C-ABI entry point against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): correspondence / mask / label / index work bit-exact; here the
+floating-point maps are ALSO required bit-exact, because the HIP kernels and the oracle evaluate
+the same IEEE operations in the same order (no FMA contraction on either side)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    if a.dtype.kind == "f":
+        ok = (a == b) | (np.isnan(a) & np.isnan(b))
+        assert ok.all(), "mismatch at %d of %d elements, max abs diff %g" % ((~ok).sum(), ok.size, np.nanmax(np.abs(a - b)))
+    else:
+        assert np.array_equal(a, b), "mismatch at %d of %d elements" % ((a != b).sum(), a.size)
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg, synth):
+    c = pkg.Context(0)
+    c.set_calibration_matrix(synth.TUM_CALIB)
+    yield c
+    c.close()
+
+
+def pose16(R, t):
+    P = np.eye(4, dtype=np.float32)
+    P[:3, :3] = R
+    P[:3, 3] = t
+    return P.T.reshape(-1).copy()  # column-major
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(480, 640), (37, 53), (5, 130)])
+def test_preprocess(ctx, orc, synth, shape):
+    n, m = shape
+    calib = synth.calib_for(n, m)
+    ctx.set_calibration_matrix(calib)
+    d, c = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    d[::7, ::5] = 0  # holes
+    vmap = torch.empty(n, m, 3, device="cuda")
+    rgb = torch.empty(n, m, 3, device="cuda")
+    nmap = torch.empty(n, m, 3, device="cuda")
+    ctx.vertex_map_kinect(vmap, dev(d), 2 * m, n, m)
+    ctx.gpu_cpy_char3(dev(c), 3 * m, rgb, n, m)
+    ctx.compute_normal(nmap, vmap, n, m, True)
+    ctx.synchronize()
+    v_ref = orc.vertex_map_kinect(d, calib)
+    same(host(vmap), v_ref)
+    same(host(rgb), orc.cpy_char3(c))
+    same(host(nmap), orc.compute_normal(v_ref))
+    ctx.compute_normal(nmap, vmap, n, m, False)
+    same(host(nmap), orc.compute_normal(v_ref, False))
+    img = torch.empty(n, m, device="cuda")
+    gx = torch.empty(n, m, device="cuda")
+    gy = torch.empty(n, m, device="cuda")
+    ctx.intensity_sobel(rgb, img, gx, gy, n, m)
+    ri, rx, ry = orc.intensity_sobel(host(rgb))
+    same(host(img), ri)
+    same(host(gx), rx)
+    same(host(gy), ry)
+    ctx.set_calibration_matrix(synth.TUM_CALIB)
+
+
+def test_pitched_inputs(ctx, orc, synth):
+    n, m = 48, 70
+    calib = synth.calib_for(n, m)
+    ctx.set_calibration_matrix(calib)
+    d, c = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    dp = np.zeros((n, 96), np.uint16)
+    dp[:, :m] = d
+    cp = np.zeros((n, 256), np.uint8)
+    cp[:, :3 * m] = c.reshape(n, 3 * m)
+    vmap = torch.empty(n, m, 3, device="cuda")
+    rgb = torch.empty(n, m, 3, device="cuda")
+    ctx.vertex_map_kinect(vmap, dev(dp), 2 * 96, n, m)
+    ctx.gpu_cpy_char3(dev(cp), 256, rgb, n, m)
+    same(host(vmap), orc.vertex_map_kinect(d, calib))
+    same(host(rgb), orc.cpy_char3(c))
+    ctx.set_calibration_matrix(synth.TUM_CALIB)
+
+
+@pytest.mark.parametrize("fact", [4, 2, 1])
+def test_icp_system_bit_exact(ctx, orc, pair, fact):
+    n, m = 480, 640
+    calib = pair["calib"]
+    R = np.eye(3, dtype=np.float32).T.reshape(-1)
+    t = np.zeros(3, np.float32)
+    gr, gc = orc.icp_grid(n, m, 1)
+    ctx.alloc_buffers(gr, gc)
+    corr = torch.empty(n, m, dtype=torch.int32, device="cuda")
+    A, b = ctx.estimate_system(dev(R), dev(t), dev(pair["v1"]), dev(pair["n1"]), dev(pair["rgb1"]), dev(pair["gx1"]),
+                               dev(pair["gy1"]), dev(pair["v0"]), dev(pair["n0"]), dev(pair["rgbd0"]), dev(calib[:4]),
+                               0.05, float(np.sin(np.deg2rad(20.0))), n, m, fact, corr)
+    A_ref, b_ref, _ = orc.estimate_system(calib[:4], R, t, pair["v1"], pair["n1"], pair["rgb1"], pair["gx1"], pair["gy1"],
+                                          pair["v0"], pair["n0"], pair["rgbd0"], 0.05, float(np.sin(np.deg2rad(20.0))), fact)
+    _, corr_ref = orc.icp_match(calib[:4], R, t, pair["v1"], pair["n1"], pair["rgb1"], pair["gx1"], pair["gy1"],
+                                pair["v0"], pair["n0"], pair["rgbd0"], 0.05, float(np.sin(np.deg2rad(20.0))), fact)
+    same(host(corr), corr_ref)                      # correspondence indices bit-exact
+    assert (corr_ref >= 0).sum() > 1000
+    same(np.array(A, np.float32).reshape(6, 6), A_ref)   # 27 sums bit-identical (reference order)
+    same(np.array(b, np.float32), b_ref)
+
+
+def test_icp_system_rotated_estimate(ctx, orc, pair):
+    """A non-identity Rcurr/tcurr exercises the column-major indexing of ICP.cu:98-104."""
+    n, m = 480, 640
+    calib = pair["calib"]
+    Rm = np.linalg.inv(pair["R1"]).astype(np.float32)
+    R = Rm.T.reshape(-1).copy()
+    t = (-Rm @ pair["t1"]).astype(np.float32)
+    gr, gc = orc.icp_grid(n, m, 1)
+    ctx.alloc_buffers(gr, gc)
+    A, b = ctx.estimate_system(dev(R), dev(t), dev(pair["v1"]), dev(pair["n1"]), dev(pair["rgb1"]), dev(pair["gx1"]),
+                               dev(pair["gy1"]), dev(pair["v0"]), dev(pair["n0"]), dev(pair["rgbd0"]), dev(calib[:4]),
+                               0.05, 0.342, n, m, 2)
+    A_ref, b_ref, _ = orc.estimate_system(calib[:4], R, t, pair["v1"], pair["n1"], pair["rgb1"], pair["gx1"], pair["gy1"],
+                                          pair["v0"], pair["n0"], pair["rgbd0"], 0.05, 0.342, 2)
+    same(np.array(A, np.float32).reshape(6, 6), A_ref)
+    same(np.array(b, np.float32), b_ref)
+
+
+def test_align_device_loop(ctx, pkg, orc, pair):
+    """Whole Gauss-Newton loop on the device vs RG::AlignFrameGaussNewton restated on the CPU."""
+    n, m = 480, 640
+    calib = pair["calib"]
+    gr, gc = orc.icp_grid(n, m, 1)
+    ctx.alloc_buffers(gr, gc)
+    I = np.eye(3, dtype=np.float32).reshape(-1)
+    z = np.zeros(3, np.float32)
+    state = dev(np.concatenate([I, z, I, z]).astype(np.float32))
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    trace = torch.zeros(16, 33, device="cuda")
+    prm = pkg.icp_params()
+    ctx.align_gauss_newton(prm, dev(pair["v1"]), dev(pair["n1"]), dev(pair["rgb1"]), dev(pair["gx1"]), dev(pair["gy1"]),
+                           dev(pair["v0"]), dev(pair["n0"]), dev(pair["rgbd0"]), n, m, state, status, trace)
+    ctx.synchronize()
+    ok, R, t, tr = orc.align_gauss_newton(orc.icp_params(), calib[:4], pair["v1"], pair["n1"], pair["rgb1"], pair["v0"],
+                                          pair["n0"], pair["rgbd0"], I, z, I, z)
+    st = host(status)
+    assert ok and st[0] == 1
+    assert st[1] == len(tr)
+    same(host(trace)[:len(tr)], tr)                 # every iteration's sums and solution
+    s = host(state)
+    same(s[:9], R)
+    same(s[9:12], t)
+    # and the pose is the known offset up to depth quantisation
+    assert np.linalg.norm(s[:9].reshape(3, 3).T - pair["R1"]) < 5e-5
+    assert np.linalg.norm(s[9:12] - pair["t1"]) < 5e-5
+
+
+def test_align_track_loss(ctx, pkg, orc, pair):
+    n, m = 480, 640
+    gr, gc = orc.icp_grid(n, m, 1)
+    ctx.alloc_buffers(gr, gc)
+    I = np.eye(3, dtype=np.float32).reshape(-1)
+    z = np.zeros(3, np.float32)
+    state = dev(np.concatenate([I, z, I, z]).astype(np.float32))
+    status = torch.ones(4, dtype=torch.int32, device="cuda")
+    empty = torch.zeros(n, m, 3, device="cuda")   # no normals at all -> singular system
+    ctx.align_gauss_newton(pkg.icp_params(), empty, empty, empty, dev(pair["gx1"]), dev(pair["gy1"]),
+                           dev(pair["v0"]), dev(pair["n0"]), dev(pair["rgbd0"]), n, m, state, status)
+    ctx.synchronize()
+    assert host(status)[0] == 0
+    same(host(state)[:12], np.concatenate([I, z]))   # pose kept (GP-demo.cpp:189-196)
+    ok, _, _, _ = orc.align_gauss_newton(orc.icp_params(), pair["calib"][:4], host(empty), host(empty), host(empty),
+                                         pair["v0"], pair["n0"], pair["rgbd0"], I, z, I, z)
+    assert not ok
+
+
+def test_merge_and_model_maps(ctx, orc, pair, synth):
+    n, m = 480, 640
+    calib = pair["calib"]
+    rng = np.random.default_rng(1)
+    rgbd = pair["rgbd0"].copy()
+    # perturb the predicted depth to hit every branch: equal, occluded, violated, empty
+    w = rgbd[..., 3]
+    w[100:200] *= 1.5
+    w[200:300] *= 0.5
+    w[300:350] = 0
+    w[350:400] += rng.normal(0, 1e-5, w[350:400].shape).astype(np.float32)
+    mask = rng.integers(9, 256, (n, m)).astype(np.uint8)
+    mask[::3] = 11
+    mask[1::9] = 1
+    mask[2::9] = 255
+    g_rgbd, g_mask = dev(rgbd), dev(mask)
+    ctx.merge_depth_off(g_rgbd, dev(pair["d1"]), 2 * m, dev(pair["rgb1"]), g_mask, n, m)
+    r_rgbd, r_mask = orc.merge_depth_off(rgbd, pair["d1"], pair["rgb1"], mask, calib)
+    same(host(g_mask), r_mask)
+    same(host(g_rgbd), r_rgbd)
+    assert len(np.unique(r_mask)) > 5
+    vmap = torch.empty(n, m, 3, device="cuda")
+    ctx.vertex_map_gl(vmap, g_rgbd, n, m)
+    same(host(vmap), orc.vertex_map_gl(r_rgbd, calib))
+    out = torch.empty(n, m, 4, device="cuda")
+    ctx.gpu_add_zbuff_off(dev(pair["d1"]), 2 * m, dev(pair["rgb1"]), out, n, m)
+    ref = orc.add_zbuff_off(pair["d1"], pair["rgb1"], calib)
+    same(host(out), ref)
+    mk = torch.empty(n, m, dtype=torch.uint8, device="cuda")
+    ctx.init_mask(mk, out, n, m)
+    same(host(mk), orc.init_mask(ref))
+
+
+def _rel_pose(pair):
+    Rinv = np.linalg.inv(pair["R1"])
+    return pose16(Rinv, -Rinv @ pair["t1"])
+
+
+def test_transform_trim_raster_read(ctx, orc, pair):
+    n, m = 480, 640
+    calib = pair["calib"]
+    P = _rel_pose(pair)
+    v = pair["v0"].copy()
+    v[50:60, 70:90] = 0            # a hole
+    v[200:260, 300:380, 2] += 0.5  # a foreground box -> discontinuities + occlusion after the warp
+    v[200:260, 300:380, :2] *= (v[200:260, 300:380, 2:3] / (v[200:260, 300:380, 2:3] - 0.5))
+    g_v, g_rgbd = dev(v), dev(pair["rgbd0"])
+    ctx.set_pose_matrix(P)
+    ctx.transform_vertex_map(g_v, g_rgbd, n, m)
+    r_v, r_rgbd = orc.transform_vertex_map(P, v, pair["rgbd0"])
+    same(host(g_v), r_v)
+    same(host(g_rgbd), r_rgbd)
+    idx = torch.empty((n - 1) * (m - 1), 4, dtype=torch.int32, device="cuda")
+    ctx.quad_trim_frame(g_v, idx, n, m, 0.1)
+    r_idx = orc.quad_trim_frame(r_v, 0.1)
+    same(host(idx).view(np.uint32), r_idx)
+    assert (r_idx.sum(1) == 0).sum() > 100
+    zbuf = torch.empty(n, m, dtype=torch.int64, device="cuda")
+    tex = torch.empty(n, m, 4, device="cuda")
+    ctx.raster_clear(zbuf, n, m)
+    # inline trimming
+    ctx.predict_raster(tex, zbuf, g_v, g_rgbd, None, n, m)
+    r_tex, _ = orc.raster(r_v, r_rgbd, calib)
+    same(host(tex), r_tex)
+    assert (host(zbuf) == -1).all()                 # z-buffer left clean for the next frame
+    assert (r_tex[..., 3] > 0).mean() > 0.9
+    # explicit GL_QUADS index buffer
+    tex2 = torch.empty(n, m, 4, device="cuda")
+    ctx.predict_raster(tex2, zbuf, g_v, g_rgbd, idx, n, m)
+    r_tex2, _ = orc.raster(r_v, r_rgbd, calib, index=r_idx)
+    same(host(tex2), r_tex2)
+    same(r_tex2, r_tex)
+    ctx.read_frame(g_v, g_rgbd, tex, n, m)
+    rv2, rr2 = orc.read_frame(r_tex, calib)
+    same(host(g_v), rv2)
+    same(host(g_rgbd), rr2)
+
+
+def test_project_mask_and_segment(ctx, orc, pair, synth):
+    n, m = 480, 640
+    calib = pair["calib"]
+    rng = np.random.default_rng(2)
+    mask = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    P = pose16(pair["R1"], pair["t1"] * 20)   # large enough shift to push projections off-image
+    ctx.set_pose_matrix(P)
+    out = torch.empty(n, m, dtype=torch.uint8, device="cuda")
+    ctx.project_mask(dev(mask), out, dev(pair["v0"]), n, m)
+    ref = orc.project_mask(P, calib, mask, pair["v0"])
+    same(host(out), ref)
+    assert (ref == 0).sum() > 500
+    eq, _ = synth.plane_equations()
+    I16 = pose16(np.eye(3), np.zeros(3))
+    lab = torch.empty(n, m, dtype=torch.uint8, device="cuda")
+    ctx.seed_labels(lab, dev(pair["v0"]), dev(pair["n0"]), I16, dev(eq), 3, n, m)
+    lab_ref = orc.seed_labels(pair["v0"], pair["n0"], I16, eq)
+    same(host(lab), lab_ref)
+    assert len(np.unique(lab_ref)) == 4
+    holes = lab_ref.copy()
+    holes[rng.random((n, m)) < 0.4] = 0
+    holes[100:140, 100:160] = 0
+    g_lab, swap = dev(holes), torch.empty(n, m, dtype=torch.uint8, device="cuda")
+    ctx.segment(g_lab, swap, dev(pair["v0"]), dev(pair["n0"]), I16, dev(eq), 3, n, m, 0.1, 0.9)
+    seg_ref = orc.segment(holes, pair["v0"], pair["n0"], I16, eq, 0.1, 0.9)
+    same(host(g_lab), seg_ref)
+    assert (seg_ref > 0).sum() > (holes > 0).sum()
+
+
+def _plane_setup(synth, N_prim, nb=3):
+    eq, cen = synth.plane_equations()
+    params = []
+    for k in range(nb):
+        E, c = eq[k], cen[k]
+        scale = np.float32(2.0 / 0.004)
+        pt0 = np.float32(c @ E[3:6])
+        pt1 = np.float32(c @ E[6:9])
+        sh0 = np.float32(pt0 - N_prim * 0.004 / 2.0)
+        sh1 = np.float32(pt1 - N_prim * 0.004 / 2.0)
+        params.append(np.array([E[0], E[1], E[2], E[9], scale, scale, sh0, sh1, E[3], E[4], E[5], E[6], E[7], E[8]], np.float32))
+    return eq, params
+
+
+def _ptr_table(tensors):
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device="cuda")
+
+
+def test_update_and_decode(ctx, orc, pair, synth):
+    n, m = 480, 640
+    N_prim = 1024
+    eq, params = _plane_setup(synth, N_prim)
+    I16 = pose16(np.eye(3), np.zeros(3))
+    label = orc.seed_labels(pair["v0"], pair["n0"], I16, eq)
+    rng = np.random.default_rng(3)
+    rgbd = pair["rgbd0"]
+    bumps = [np.zeros((N_prim, N_prim, 3), np.uint16) for _ in range(3)]
+    rgbs = [np.zeros((N_prim, N_prim, 3), np.uint8) for _ in range(3)]
+    masks = [np.zeros((N_prim, N_prim), np.uint8) for _ in range(3)]
+    claims = [np.zeros((N_prim, N_prim), np.uint64) for _ in range(3)]
+    g_b, g_c, g_m = [dev(x) for x in bumps], [dev(x) for x in rgbs], [dev(x) for x in masks]
+    g_k = [torch.zeros(N_prim, N_prim, dtype=torch.int64, device="cuda") for _ in range(3)]
+    g_p = [dev(p) for p in params]
+    tabs = [_ptr_table(x) for x in (g_b, g_c, g_m, g_p, g_k)]
+    g_v, g_rgbd, g_lab = dev(pair["v0"]), dev(rgbd), dev(label)
+    # three rounds: fresh write (mask 11..14), higher-confidence overwrite, then erosion (mask 0)
+    for stamp, maskgen in enumerate([lambda: rng.integers(11, 15, (n, m)), lambda: rng.integers(10, 40, (n, m)),
+                                     lambda: np.where(rng.random((n, m)) < 0.5, 0, rng.integers(10, 60, (n, m)))], start=1):
+        mk = maskgen().astype(np.uint8)
+        ctx.update(tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], stamp, g_v, g_rgbd, dev(mk), g_lab, I16, N_prim, N_prim, n, m)
+        orc.update(bumps, rgbs, masks, params, claims, stamp, pair["v0"], rgbd, mk, label, I16)
+        for k in range(3):
+            same(host(g_m[k]), masks[k])
+            same(host(g_b[k]), bumps[k])
+            same(host(g_c[k]), rgbs[k])
+    assert sum((mk_ > 10).sum() for mk_ in masks) > 50000
+    # decode (VertexFromBump) incl. the special mask value 1 and sub-sampling
+    masks[0][10:20, 10:20] = 1
+    g_m[0].copy_(dev(masks[0]))
+    for lvl in (1, 2):
+        no = N_prim // lvl
+        v = torch.empty(no, no, 3, device="cuda")
+        c = torch.empty(no, no, 4, device="cuda")
+        k4 = torch.empty(no, no, 4, device="cuda")
+        ctx.vertex_from_bump(v, c, k4, g_b[0], g_c[0], g_m[0], g_p[0], N_prim, N_prim, lvl)
+        rv, rc, rk = orc.vertex_from_bump(bumps[0], rgbs[0], masks[0], params[0], lvl)
+        same(host(v), rv)
+        same(host(c), rc)
+        same(host(k4), rk)
+
+
+def test_update_plane_partition(ctx, orc, pair, synth):
+    """Plane-partitioned fusion: shards [0,1) and [1,3) together equal the unpartitioned result."""
+    n, m = 480, 640
+    N_prim = 512
+    eq, params = _plane_setup(synth, N_prim)
+    I16 = pose16(np.eye(3), np.zeros(3))
+    label = orc.seed_labels(pair["v0"], pair["n0"], I16, eq)
+    mk = np.full((n, m), 12, np.uint8)
+
+    def run(parts):
+        g_b = [torch.zeros(N_prim, N_prim, 3, dtype=torch.int16, device="cuda") for _ in range(3)]
+        g_c = [torch.zeros(N_prim, N_prim, 3, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        g_m = [torch.zeros(N_prim, N_prim, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        g_k = [torch.zeros(N_prim, N_prim, dtype=torch.int64, device="cuda") for _ in range(3)]
+        g_p = [dev(p) for p in params]
+        tabs = [_ptr_table(x) for x in (g_b, g_c, g_m, g_p, g_k)]
+        for lo, hi in parts:
+            ctx.update(tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], 1, dev(pair["v0"]), dev(pair["rgbd0"]), dev(mk),
+                       dev(label), I16, N_prim, N_prim, n, m, lo, hi)
+        return [host(x) for x in g_b + g_c + g_m]
+
+    full = run([(0, 2 ** 31 - 1)])
+    parts = run([(0, 1), (1, 3)])
+    for a, b in zip(full, parts):
+        same(a, b)
+
+
+def test_argument_errors(ctx, pkg):
+    lib = pkg.load()
+    assert lib.rgbdslam_compute_normal(ctx._h, None, None, 480, 640, 1) == 1
+    assert lib.rgbdslam_vertex_map_gl(ctx._h, None, None, 0, 0) == 1
+    assert lib.rgbdslam_create(None, 0, None) == 1
