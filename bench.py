@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP+fusion frames/s at 640x480 (BASELINE.json metric) on N MI355X GPUs.
+
+One "step" = one full pass of the hot path over one RGB-D frame, i.e. one display() iteration of
+the reference (D1/GP-demo.cpp:138-296): preprocess -> 3-level Gauss-Newton ICP (27-term reduction,
+6x6 solve) -> warp + rasterised prediction -> mask/label re-projection -> depth merge -> Bump-image
+fusion into 3 planes of 1024x1024 cells.  Workload = BASELINE.json configs[1] (TUM fr1/xyz-shaped
+640x480 sequence, synthetic).  Frames are resident in HBM before the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): configs[4] -- every rank tracks its
+own independent sequence (no data-path collective; "weak" scaling); value = all ranks' frames / max
+time over ranks.
+
+The JSON line also carries
+  roofline     -- the dominant kernel's algorithmic bytes / its HIP-event duration (events recorded
+                  on the library's stream around every launch of that kernel) vs. 8 TB/s HBM3E;
+  cpu_baseline -- the CPU oracle (scalar C port of the reference arithmetic, 1 thread) timed on a
+                  bounded sample of the same sequence on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+POOL_FRAMES = 60           # distinct synthetic frames, visited ping-pong so steps stay <= 1 cm / 1 deg
+
+# Algorithmic bytes per unit (SURVEY.md 8d / DESIGN.md "kernels"), per launch of each kernel.
+def algo_bytes(kernel, n, m, level_iters):
+    P = n * m
+    if kernel == "k_icp_match":
+        # 80 B per sampled model pixel per executed iteration, all three levels summed
+        return sum(80 * (n // f) * (m // f) * it for f, it in zip((1, 2, 4), level_iters))
+    per_px = {"k_update<false>": 30, "k_update<true>": 41, "k_merge_depth_off": 48, "k_compute_normal": 24,
+              "k_raster_draw": 28, "k_raster_resolve": 72, "k_read_frame": 44, "k_transform_vertex_map": 28,
+              "k_project_mask": 14, "k_segment_pass": 26, "k_vertex_map_gl": 16, "k_vertex_map_kinect": 14,
+              "k_cpy_char3": 15, "k_intensity_sobel": 20}
+    return per_px[kernel] * P
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--rows", type=int, default=480)
+    ap.add_argument("--cols", type=int, default=640)
+    ap.add_argument("--kernel", default="k_icp_match", help="kernel whose roofline is reported")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--profile-in-timed-region", action="store_true",
+                    help="record the roofline events inside the timed region instead of in a second pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pkg = importlib.import_module("rgb-d-slam_amd")
+    synth = importlib.import_module("rgb-d-slam_amd.synth")
+    n, m = args.rows, args.cols
+    calib = synth.calib_for(n, m)
+    pool = synth.sequence(POOL_FRAMES, n, m, calib, noise_sigma=0.001, seed=rank)
+    total = args.warmup + args.steps + 1
+    order = []
+    k, d = 0, 1
+    for _ in range(total + args.steps):
+        order.append(k)
+        if k + d < 0 or k + d >= POOL_FRAMES:
+            d = -d
+        k += d
+    depth_dev = [torch.from_numpy(p[0]).cuda() for p in pool]
+    bgr_dev = [torch.from_numpy(p[1]).cuda() for p in pool]
+
+    stream = torch.cuda.Stream()
+    rg = pkg.RG(n, m, calib, device=local, stream=stream.cuda_stream)
+    host = pkg.load_host()
+    lib = pkg.load()
+    host.slamhost_rg_ctx.restype = C.c_void_p
+    ctx = C.c_void_p(host.slamhost_rg_ctx(rg._h))
+    eq, centers = synth.plane_equations()
+
+    def run(frames):
+        return rg.run_device_sequence([depth_dev[i] for i in frames], [bgr_dev[i] for i in frames])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # frame 0 seeds the model; planes are injected once (plane detection is SURVEY 8f "next")
+    run(order[:1])
+    rg.set_planes(eq, centers)
+    pos = 1
+    run(order[pos:pos + args.warmup])
+    pos += args.warmup
+    if args.profile_in_timed_region:
+        lib.rgbdslam_profile_kernel(ctx, args.kernel.encode())
+    barrier()
+    t0 = time.perf_counter()
+    tracked = run(order[pos:pos + args.steps])
+    rg.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    pos += args.steps
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tr = torch.tensor([tracked], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.MIN)
+        tracked = int(tr.item())
+    if tracked != args.steps:
+        raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
+
+    # ---- roofline of the dominant kernel: HIP events around each of its launches ----
+    level_iters = [0, 0, 0]
+    if not args.profile_in_timed_region:
+        lib.rgbdslam_profile_kernel(ctx, args.kernel.encode())
+        run(order[pos:pos + args.steps])
+    li = host.slamhost_rg_last_level_iterations(rg._h)
+    level_iters = [li & 255, (li >> 8) & 255, (li >> 16) & 255]
+    tot_ms, launches = C.c_double(), C.c_int()
+    lib.rgbdslam_profile_read(ctx, C.byref(tot_ms), C.byref(launches))
+    lib.rgbdslam_profile_kernel(ctx, None)
+    per_frame_launches = launches.value / float(args.steps)
+    bytes_per_frame = algo_bytes(args.kernel, n, m, level_iters)
+    avg_ms = tot_ms.value / max(1, launches.value)
+    achieved = bytes_per_frame * args.steps / (tot_ms.value * 1e-3) / 1e9 if tot_ms.value > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": args.kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_frame": round(per_frame_launches, 2),
+                "algorithmic_bytes_per_frame": bytes_per_frame, "icp_iterations_per_level": level_iters}
+
+    # ---- CPU baseline: the oracle's display() loop on a bounded sample of the same sequence ----
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle import oracle as orc
+        ref = orc.Slam(n, m, calib)
+        ref.step(*pool[order[0]])
+        ref.set_planes(eq, centers)
+        c0 = time.perf_counter()
+        for i in order[1:1 + args.cpu_frames]:
+            ref.step(*pool[i])
+        cdt = time.perf_counter() - c0
+        ref.close()
+        cpu = {"value": round(args.cpu_frames / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d frames of the same %dx%d sequence, oracle display() loop (scalar C, -O2, 1 thread)"
+                         % (args.cpu_frames, m, n)}
+
+    if rank == 0:
+        out = {"metric": "ICP+fusion frames/sec at 640x480", "value": round(world * args.steps / dt, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "TUM fr1/xyz-shaped %dx%d RGB-D sequence (synthetic room corner, 1 mm depth noise), 3-level ICP "
+                                      "(<= 3/4/5 iterations) + prediction + merge + Bump fusion into 3 planes of 1024x1024"
+                                      % (m, n),
+                          "sequences": world, "frames_resident_in_hbm": True},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    rg.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,8 +40,15 @@ typedef struct rgbdslam_ctx rgbdslam_ctx;
 int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream);
 int rgbdslam_destroy(rgbdslam_ctx *ctx);
 int rgbdslam_set_stream(rgbdslam_ctx *ctx, void *stream);
+int rgbdslam_get_stream(rgbdslam_ctx *ctx, void **stream);
 int rgbdslam_synchronize(rgbdslam_ctx *ctx);
 const char *rgbdslam_version(void);
+/* Instrumentation (no reference counterpart; the reference's only timing is clock() prints behind
+ * `#define TIMING`, Utilities.h:82): brackets every later launch of the kernel called `kernel_name`
+ * (e.g. "k_icp_match") with a HIP event pair on the context's stream.  NULL switches it off.
+ * profile_read synchronises, returns the summed durations and the launch count, and resets. */
+int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_name);
+int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *launches);
 
 /* Kernel.cuh:7-8   void SetCalibrationMatrix(float *Calib_CPU); FreeCalibrationMatrix()
  * calib = {fx, fy, cx, cy, k1..k5 (unused), ds, factor} (GP-demo.cpp:17,404). */
@@ -92,7 +99,8 @@ int rgbdslam_estimate_system_gauss_newton(rgbdslam_ctx *ctx, const float *Rcurr_
  * resident on the device (match + reduce + 6x6 solve + pose update per iteration, no host round
  * trips).  pose_state_dev = f32[24] device memory: poseR(9, col-major) poset(3) poseRPrev(9)
  * posetPrev(3); poseR/poset are updated in place on success.  status_dev = int32[4] device
- * memory: [0] 1 tracked / 0 lost, [1] iterations executed, [2..3] reserved.  Asynchronous. */
+ * memory: [0] 1 tracked / 0 lost, [1] iterations executed, [2] the same per level
+ * (8 bits each, level 0 = full resolution in the low byte), [3] reserved.  Asynchronous. */
 typedef struct rgbdslam_icp_params {
     int   lvl;                 /* 3 */
     int   max_iter[3];         /* {3,2,1}  RG.h:124-126 */

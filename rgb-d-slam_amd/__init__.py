@@ -187,3 +187,124 @@ class Context:
     def seed_labels(self, label, vmap, nmap, pose, equations, nb, n, m, eps=0.1, alpha=0.8):
         _chk(self.lib.rgbdslam_seed_labels(self._h, _ptr(label), _ptr(vmap), _ptr(nmap), _host16(pose), _ptr(equations), nb,
                                            C.c_float(eps), C.c_float(alpha), n, m), "seed_labels")
+
+
+# ---- host classes (librgbdslam_host.so: C++ mirror of RG / Frame / Graph / Primitive) ---------------
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is None:
+        load()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError("librgbdslam_host.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _host = C.CDLL(HOST_LIB_PATH)
+        _host.slamhost_last_error.restype = C.c_char_p
+    return _host
+
+
+def _hchk(rc, what):
+    if rc != 0:
+        raise SlamError("%s failed with code %d: %s" % (what, rc, (load_host().slamhost_last_error() or b"").decode()))
+
+
+class RG:
+    """ctypes handle on the C++ `slam::RG` (D1/RG.h) -- the reference's reconstruction driver plus
+    the display() loop (D1/GP-demo.cpp:138-296) as `step()`."""
+
+    BUFFER_DTYPES = {"VMap": ("float32", 3), "NMap": ("float32", 3), "RGBD": ("float32", 4), "Mask": ("uint8", 1),
+                     "Label": ("uint8", 1), "frame.VMap": ("float32", 3), "frame.NMap": ("float32", 3),
+                     "frame.RGB": ("float32", 3)}
+
+    def __init__(self, n, m, calib, lvl=3, dist=0.05, angle=0.3420201433256687, device=0, stream=None, max_planes=50,
+                 N_prim=1024, M_prim=1024):
+        self.lib = load_host()
+        self.n, self.m, self.N_prim, self.M_prim = n, m, N_prim, M_prim
+        self._h = C.c_void_p()
+        _hchk(self.lib.slamhost_rg_create(C.byref(self._h), int(device), C.c_void_p(stream or 0), n, m, _host16(calib), lvl,
+                                          C.c_float(dist), C.c_float(angle), max_planes, N_prim, M_prim), "rg_create")
+
+    def close(self):
+        if self._h:
+            self.lib.slamhost_rg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_device_loop(self, on):
+        _hchk(self.lib.slamhost_rg_set_device_loop(self._h, int(on)), "set_device_loop")
+
+    def set_index_buffer(self, on):
+        _hchk(self.lib.slamhost_rg_set_index_buffer(self._h, int(on)), "set_index_buffer")
+
+    def set_plane_range(self, lo, hi):
+        _hchk(self.lib.slamhost_rg_set_plane_range(self._h, int(lo), int(hi)), "set_plane_range")
+
+    def load_frame(self, depth_np, bgr_np):
+        """Host images (numpy u16 [n,m], u8 [n,m,3]); uploaded like GpuMat::upload (D1/Frame.cpp:56-60)."""
+        self._keep = (depth_np, bgr_np)
+        _hchk(self.lib.slamhost_rg_load_frame(self._h, C.c_void_p(depth_np.ctypes.data), C.c_void_p(bgr_np.ctypes.data)),
+              "load_frame")
+
+    def load_frame_device(self, depth_t, bgr_t, depth_pitch=None, bgr_pitch=None):
+        _hchk(self.lib.slamhost_rg_load_frame_device(self._h, _ptr(depth_t), C.c_size_t(depth_pitch or 2 * self.m), _ptr(bgr_t),
+                                                     C.c_size_t(bgr_pitch or 3 * self.m)), "load_frame_device")
+
+    def set_planes(self, equations, centers):
+        eq = [float(x) for x in equations.reshape(-1)]
+        ce = [float(x) for x in centers.reshape(-1)]
+        _hchk(self.lib.slamhost_rg_set_planes(self._h, _host16(eq), _host16(ce), len(eq) // 10), "set_planes")
+
+    def step(self):
+        st = C.c_int()
+        _hchk(self.lib.slamhost_rg_step(self._h, C.byref(st)), "step")
+        return st.value
+
+    def run_device_sequence(self, depth_ts, bgr_ts):
+        k = len(depth_ts)
+        dt = (C.c_void_p * k)(*[t.data_ptr() for t in depth_ts])
+        bt = (C.c_void_p * k)(*[t.data_ptr() for t in bgr_ts])
+        ok = C.c_int()
+        _hchk(self.lib.slamhost_rg_run_device_sequence(self._h, dt, bt, k, C.c_size_t(2 * self.m), C.c_size_t(3 * self.m),
+                                                       C.byref(ok)), "run_device_sequence")
+        return ok.value
+
+    def synchronize(self):
+        _hchk(self.lib.slamhost_rg_synchronize(self._h), "synchronize")
+
+    def pose(self):
+        R = (C.c_float * 9)()
+        t = (C.c_float * 3)()
+        _hchk(self.lib.slamhost_rg_get_pose(self._h, R, t), "get_pose")
+        return list(R), list(t)
+
+    def last_iterations(self):
+        return self.lib.slamhost_rg_last_iterations(self._h)
+
+    def buffer_ptr(self, name):
+        p = C.c_void_p()
+        nb = C.c_size_t()
+        _hchk(self.lib.slamhost_rg_buffer(self._h, name.encode(), C.byref(p), C.byref(nb)), "buffer(%s)" % name)
+        return p.value, nb.value
+
+    def buffer(self, name):
+        """Copies a named device buffer to a numpy array (torch-free)."""
+        import numpy as np
+        ptr, nb = self.buffer_ptr(name)
+        self.synchronize()
+        out = np.empty(nb, np.uint8)
+        _hchk(self.lib.slamhost_copy_to_host(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nb)), "copy_to_host")
+        if name in self.BUFFER_DTYPES:
+            dt, ch = self.BUFFER_DTYPES[name]
+            a = out.view(dt)
+            return a.reshape(self.n, self.m, ch) if ch > 1 else a.reshape(self.n, self.m)
+        if name.startswith("Bump"):
+            return out.view("uint16").reshape(self.N_prim, self.M_prim, 3)
+        if name.startswith("RGBb"):
+            return out.reshape(self.N_prim, self.M_prim, 3)
+        return out.reshape(self.N_prim, self.M_prim)

@@ -24,7 +24,7 @@ struct IcpState {
     float Rinv[9], tinv[3];    // Rcurr_inv, tcurr_inv
     float Rcurr[9], tcurr[3];  // the pair uploaded for the current iteration (RG.cpp:851-855)
     float intr[4];
-    int   cvg, fail, iters, pad;
+    int   cvg, fail, iters, lvl_iters;   // lvl_iters: executed iterations per level, 8 bits each
 };
 
 struct rgbdslam_ctx {
@@ -39,7 +39,22 @@ struct rgbdslam_ctx {
     float *outbuf_dev;   // f32[27]
     float *out_host;     // pinned f32[27]
     IcpState *icp_state; // device
+    // instrumentation (rgbdslam_profile_*): HIP-event pairs around every launch of one named kernel
+    const char *prof_name;
+    hipEvent_t *prof_ev;   // 2 * prof_cap events
+    int prof_cap, prof_n;
 };
+
+// Launch on the context's stream; when the kernel's name is the one being profiled, bracket the
+// launch with a HIP event pair recorded on that same stream.
+bool prof_begin(rgbdslam_ctx *ctx, const char *kname);
+void prof_end(rgbdslam_ctx *ctx);
+#define KLAUNCH(ctx, kern, grid, block, ...)                                         \
+    do {                                                                             \
+        bool _prof = (ctx)->prof_name && prof_begin((ctx), #kern);                   \
+        hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);        \
+        if (_prof) prof_end(ctx);                                                    \
+    } while (0)
 
 #define HIP_TRY(expr)                                     \
     do {                                                  \

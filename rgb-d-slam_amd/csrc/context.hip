@@ -2,6 +2,8 @@
 // (calib_dev/pose_dev D1/Kernel.cu:6-7, buf_dev/outbuf_dev/buf D1/ICP.cu:5-7).
 #include "common.hpp"
 #include <new>
+#include <string.h>
+#include <stdlib.h>
 
 extern "C" const char *rgbdslam_version(void) { return "rgbdslam-hip 0.1 (gfx950)"; }
 
@@ -18,6 +20,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->have_calib = false;
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->buf_dev = nullptr; c->buf_blocks = 0; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr;
+    c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0;
     *out = c;
     return 0;
 }
@@ -25,6 +28,9 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
 extern "C" int rgbdslam_destroy(rgbdslam_ctx *ctx) {
     if (!ctx) return RGBDSLAM_E_ARG;
     rgbdslam_free_buffers(ctx);
+    rgbdslam_profile_kernel(ctx, nullptr);
+    for (int k = 0; k < 2 * ctx->prof_cap; k++) (void)hipEventDestroy(ctx->prof_ev[k]);
+    free(ctx->prof_ev);
     delete ctx;
     return 0;
 }
@@ -32,6 +38,12 @@ extern "C" int rgbdslam_destroy(rgbdslam_ctx *ctx) {
 extern "C" int rgbdslam_set_stream(rgbdslam_ctx *ctx, void *stream) {
     if (!ctx) return RGBDSLAM_E_ARG;
     ctx->stream = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" int rgbdslam_get_stream(rgbdslam_ctx *ctx, void **stream) {
+    if (!ctx || !stream) return RGBDSLAM_E_ARG;
+    *stream = (void *)ctx->stream;
     return 0;
 }
 
@@ -51,5 +63,47 @@ extern "C" int rgbdslam_set_calibration_matrix(rgbdslam_ctx *ctx, const float *c
 extern "C" int rgbdslam_set_pose_matrix(rgbdslam_ctx *ctx, const float *pose16) {
     if (!ctx || !pose16) return RGBDSLAM_E_ARG;
     for (int k = 0; k < 16; k++) ctx->pose.v[k] = pose16[k];
+    return 0;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------------
+bool prof_begin(rgbdslam_ctx *ctx, const char *kname) {
+    if (strcmp(ctx->prof_name, kname) != 0) return false;
+    if (ctx->prof_n == ctx->prof_cap) {
+        int cap = ctx->prof_cap ? 2 * ctx->prof_cap : 1024;
+        hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * cap);
+        if (!ev) return false;
+        ctx->prof_ev = ev;
+        for (int k = 2 * ctx->prof_cap; k < 2 * cap; k++)
+            if (hipEventCreate(&ev[k]) != hipSuccess) return false;
+        ctx->prof_cap = cap;
+    }
+    return hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream) == hipSuccess;
+}
+void prof_end(rgbdslam_ctx *ctx) {
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream);
+    ctx->prof_n++;
+}
+
+extern "C" int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_name) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    free((void *)ctx->prof_name);
+    ctx->prof_name = kernel_name ? strdup(kernel_name) : nullptr;
+    ctx->prof_n = 0;
+    return 0;
+}
+
+extern "C" int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *launches) {
+    if (!ctx || !total_ms || !launches) return RGBDSLAM_E_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (int k = 0; k < ctx->prof_n; k++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[2 * k], ctx->prof_ev[2 * k + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = ctx->prof_n;
+    ctx->prof_n = 0;
     return 0;
 }

@@ -123,10 +123,10 @@ extern "C" int rgbdslam_update(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **
     if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;   // 23-bit pixel index in the claim key
     PoseV P; for (int k = 0; k < 16; k++) P.v[k] = pose[k];
-    hipLaunchKernelGGL(k_update<false>, grid2d(n, m), block2d(), 0, ctx->stream, BumpTab, RGBTab, MaskTab, ParamTab,
+    KLAUNCH(ctx, k_update<false>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab,
                        (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, N_prim, M_prim, n, m,
                        plane_lo, plane_hi);
-    hipLaunchKernelGGL(k_update<true>, grid2d(n, m), block2d(), 0, ctx->stream, BumpTab, RGBTab, MaskTab, ParamTab,
+    KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab,
                        (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, N_prim, M_prim, n, m,
                        plane_lo, plane_hi);
     HIP_TRY(hipGetLastError());
@@ -138,7 +138,7 @@ extern "C" int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *
                                          int lvl) {
     if (!ctx || !VMap || !RGBA || !MaskOut || !Bump || !RGB_bump || !Mask || !param_dev) return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || lvl <= 0 || n / lvl <= 0 || m / lvl <= 0) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_vertex_from_bump, grid2d(n / lvl, m / lvl), block2d(), 0, ctx->stream, VMap, RGBA, MaskOut, Bump,
+    KLAUNCH(ctx, k_vertex_from_bump, grid2d(n / lvl, m / lvl), block2d(), VMap, RGBA, MaskOut, Bump,
                        RGB_bump, Mask, param_dev, n, m, lvl);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -278,7 +278,7 @@ __global__ void k_icp_begin(IcpState *st, const float *pose_state, CalibV c, int
     d_mat3_vec(st->Rinv, pose_state + 9, tmp);                // RG.cpp:835
     st->tinv[0] = -tmp[0]; st->tinv[1] = -tmp[1]; st->tinv[2] = -tmp[2];
     for (int k = 0; k < 4; k++) st->intr[k] = c.v[k];
-    st->cvg = 0; st->fail = 0; st->iters = 0;
+    st->cvg = 0; st->fail = 0; st->iters = 0; st->lvl_iters = 0;
     d_set_rt_curr(st, pose_state);
     status[0] = 0; status[1] = 0;
 }
@@ -303,6 +303,7 @@ __global__ void k_icp_solve(IcpState *st, const float *__restrict__ sums, const 
         for (int k = 0; k < 6; k++) tr[27 + k] = x[k];
     }
     st->iters = st->iters + 1;
+    st->lvl_iters = st->lvl_iters + (1 << (8 * lvl));
     double q[4];
     double nrm = (double)((x[3] * x[3] + x[4] * x[4]) + x[5] * x[5]);   // RG.cpp:875
     q[1] = x[3]; q[2] = x[4]; q[3] = x[5]; q[0] = __builtin_sqrt(1 - nrm);
@@ -336,6 +337,7 @@ __global__ void k_icp_solve(IcpState *st, const float *__restrict__ sums, const 
 __global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     status[1] = st->iters;
+    status[2] = st->lvl_iters;
     if (st->fail) { status[0] = 0; return; }
     if ((double)d_frob_minus_I(st->Rcurr) > 0.3 || (double)d_norm3(st->tcurr) > 0.3) { status[0] = 0; return; }  // RG.cpp:910
     float R[9], neg[9], t[3];
@@ -383,10 +385,10 @@ static int launch_system(rgbdslam_ctx *ctx, const float *intr, const float *R, c
     if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
     if (!ctx->buf_dev || ctx->buf_blocks < (size_t)gr * gc) return RGBDSLAM_E_STATE;
     dim3 grid((gc + ICP_WAVES - 1) / ICP_WAVES, gr);
-    hipLaunchKernelGGL(k_icp_match, grid, dim3(64 * ICP_WAVES), 0, ctx->stream, intr, R, t, VMap, NMap, RGB, Gx, gxp,
+    KLAUNCH(ctx, k_icp_match, grid, dim3(64 * ICP_WAVES), intr, R, t, VMap, NMap, RGB, Gx, gxp,
                        Gy, gyp, VMap_prev, NMap_prev, RGB_prev, distThres, angleThres, n, m, fact, gr, gc, ctx->buf_dev,
                        corr, state, iter);
-    hipLaunchKernelGGL(k_icp_reduce, dim3(27), dim3(512), 0, ctx->stream, ctx->buf_dev, ctx->outbuf_dev, gr * gc, state, iter);
+    KLAUNCH(ctx, k_icp_reduce, dim3(27), dim3(512), ctx->buf_dev, ctx->outbuf_dev, gr * gc, state, iter);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -429,7 +431,7 @@ extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp
     if (n <= 0 || m <= 0 || prm->lvl < 1 || prm->lvl > 3 || gxp < 4 * (size_t)m || gyp < 4 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib || !ctx->icp_state) return RGBDSLAM_E_STATE;
     IcpState *st = ctx->icp_state;
-    hipLaunchKernelGGL(k_icp_begin, dim3(1), dim3(64), 0, ctx->stream, st, pose_state_dev, ctx->calib, status_dev);
+    KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
     int fact = 1 << (prm->lvl - 1);                            // RG.cpp:832
     for (int lvl = prm->lvl - 1; lvl > -1; lvl--) {
         int n_it = prm->max_iter[lvl] + 2;                     // iter = 0 .. max_iter+1 (RG.cpp:889)
@@ -437,12 +439,12 @@ extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp
             int rc = launch_system(ctx, st->intr, st->Rcurr, st->tcurr, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev,
                                    NMap_prev, RGB_prev, prm->distThres, prm->angleThres, n, m, fact, nullptr, st, iter);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, st, ctx->outbuf_dev, pose_state_dev, lvl, iter,
+            KLAUNCH(ctx, k_icp_solve, dim3(1), dim3(64), st, ctx->outbuf_dev, pose_state_dev, lvl, iter,
                                prm->max_iter[lvl], prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev);
         }
         fact /= 2;
     }
-    hipLaunchKernelGGL(k_icp_end, dim3(1), dim3(64), 0, ctx->stream, st, pose_state_dev, status_dev);
+    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -274,13 +274,13 @@ static PoseV pose_from_host(const float *p) { PoseV r; for (int k = 0; k < 16; k
 
 extern "C" int rgbdslam_transform_vertex_map(rgbdslam_ctx *ctx, float *VMap, float *RGBD, int n, int m) {
     if (!ctx || !VMap || !RGBD || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_transform_vertex_map, grid2d(n, m), block2d(), 0, ctx->stream, ctx->pose, VMap, RGBD, n, m);
+    KLAUNCH(ctx, k_transform_vertex_map, grid2d(n, m), block2d(), ctx->pose, VMap, RGBD, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 extern "C" int rgbdslam_quad_trim_frame(rgbdslam_ctx *ctx, const float *VMap, uint32_t *indices, int n, int m, float thresh) {
     if (!ctx || !VMap || !indices || n < 2 || m < 2) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_quad_trim_frame, grid2d(n - 1, m - 1), block2d(), 0, ctx->stream, indices, VMap, n, m, thresh);
+    KLAUNCH(ctx, k_quad_trim_frame, grid2d(n - 1, m - 1), block2d(), indices, VMap, n, m, thresh);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -294,9 +294,9 @@ extern "C" int rgbdslam_predict_raster(rgbdslam_ctx *ctx, float *tex, uint64_t *
     if (!ctx || !tex || !zbuf || !VMap || !RGBD || n < 2 || m < 2) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x3FFFFFFFu) return RGBDSLAM_E_LIMIT;   // triangle ids are 32 bit
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_raster_draw, grid2d(n - 1, m - 1), block2d(), 0, ctx->stream, (unsigned long long *)zbuf, VMap,
+    KLAUNCH(ctx, k_raster_draw, grid2d(n - 1, m - 1), block2d(), (unsigned long long *)zbuf, VMap,
                        indices, thresh, ctx->calib, znear, zfar, n, m);
-    hipLaunchKernelGGL(k_raster_resolve, grid2d(n, m), block2d(), 0, ctx->stream, tex, (unsigned long long *)zbuf, VMap,
+    KLAUNCH(ctx, k_raster_resolve, grid2d(n, m), block2d(), tex, (unsigned long long *)zbuf, VMap,
                        RGBD, indices, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -304,14 +304,14 @@ extern "C" int rgbdslam_predict_raster(rgbdslam_ctx *ctx, float *tex, uint64_t *
 extern "C" int rgbdslam_read_frame(rgbdslam_ctx *ctx, float *VMap, float *RGBD, const float *tex, int n, int m) {
     if (!ctx || !VMap || !RGBD || !tex || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_read_frame, grid2d(n, m), block2d(), 0, ctx->stream, VMap, RGBD, tex, ctx->calib, n, m);
+    KLAUNCH(ctx, k_read_frame, grid2d(n, m), block2d(), VMap, RGBD, tex, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 extern "C" int rgbdslam_project_mask(rgbdslam_ctx *ctx, const uint8_t *mask, uint8_t *mask_swap, const float *VMap, int n, int m) {
     if (!ctx || !mask || !mask_swap || mask == mask_swap || !VMap || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_project_mask, grid2d(n, m), block2d(), 0, ctx->stream, ctx->pose, ctx->calib, mask, mask_swap, VMap, n, m);
+    KLAUNCH(ctx, k_project_mask, grid2d(n, m), block2d(), ctx->pose, ctx->calib, mask, mask_swap, VMap, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -323,7 +323,7 @@ extern "C" int rgbdslam_segment(rgbdslam_ctx *ctx, uint8_t *Label, uint8_t *Labe
     PoseV P = pose_from_host(pose);
     uint8_t *a = Label, *b = Label_swap;
     for (int pass = 0; pass < 3; pass++) {                      // D1/RG.cu:910-911
-        hipLaunchKernelGGL(k_segment_pass, grid2d(n, m), block2d(), 0, ctx->stream, a, b, VMap, NMap, P, Eq, epsilon, alpha, n, m);
+        KLAUNCH(ctx, k_segment_pass, grid2d(n, m), block2d(), a, b, VMap, NMap, P, Eq, epsilon, alpha, n, m);
         uint8_t *t = a; a = b; b = t;
     }
     HIP_TRY(hipGetLastError());
@@ -334,7 +334,7 @@ extern "C" int rgbdslam_seed_labels(rgbdslam_ctx *ctx, uint8_t *Label, const flo
                                     const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
     if (!ctx || !Label || !VMap || !NMap || !pose || !Eq || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
     if (nbPlans <= 0 || nbPlans > 255) return RGBDSLAM_E_LIMIT;
-    hipLaunchKernelGGL(k_seed_labels, grid2d(n, m), block2d(), 0, ctx->stream, Label, VMap, NMap, pose_from_host(pose), Eq,
+    KLAUNCH(ctx, k_seed_labels, grid2d(n, m), block2d(), Label, VMap, NMap, pose_from_host(pose), Eq,
                        nbPlans, epsilon, alpha, n, m);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -212,21 +212,21 @@ extern "C" int rgbdslam_vertex_map_kinect(rgbdslam_ctx *ctx, float *VMap, const 
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!VMap || !depth || pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_vertex_map_kinect, grid2d(n, m), block2d(), 0, ctx->stream, VMap, depth, pitch, ctx->calib, n, m);
+    KLAUNCH(ctx, k_vertex_map_kinect, grid2d(n, m), block2d(), VMap, depth, pitch, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 extern "C" int rgbdslam_gpu_cpy_char3(rgbdslam_ctx *ctx, const uint8_t *bgr, size_t pitch, float *rgb, int n, int m) {
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!bgr || !rgb || pitch < 3 * (size_t)m) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_cpy_char3, grid2d(n, m), block2d(), 0, ctx->stream, bgr, pitch, rgb, n, m);
+    KLAUNCH(ctx, k_cpy_char3, grid2d(n, m), block2d(), bgr, pitch, rgb, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 extern "C" int rgbdslam_compute_normal(rgbdslam_ctx *ctx, float *NMap, const float *VMap, int n, int m, int inverse) {
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!NMap || !VMap || NMap == VMap) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_compute_normal, grid2d(n, m), block2d(), 0, ctx->stream, NMap, VMap, n, m, inverse);
+    KLAUNCH(ctx, k_compute_normal, grid2d(n, m), block2d(), NMap, VMap, n, m, inverse);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -235,7 +235,7 @@ extern "C" int rgbdslam_intensity_sobel(rgbdslam_ctx *ctx, const float *rgb, flo
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!rgb || !gx || !gy || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m) return RGBDSLAM_E_ARG;
     if (img && img_pitch < 4 * (size_t)m) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_intensity_sobel, grid2d(n, m), block2d(), 0, ctx->stream, rgb, img, img_pitch, gx, gx_pitch, gy, gy_pitch, n, m);
+    KLAUNCH(ctx, k_intensity_sobel, grid2d(n, m), block2d(), rgb, img, img_pitch, gx, gx_pitch, gy, gy_pitch, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -244,7 +244,7 @@ extern "C" int rgbdslam_merge_depth_off(rgbdslam_ctx *ctx, float *RGBD, const ui
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!RGBD || !depth || !RGB || !mask || pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_merge_depth_off, grid2d(n, m), block2d(), 0, ctx->stream, RGBD, depth, pitch, RGB, mask, ctx->calib, n, m);
+    KLAUNCH(ctx, k_merge_depth_off, grid2d(n, m), block2d(), RGBD, depth, pitch, RGB, mask, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -252,7 +252,7 @@ extern "C" int rgbdslam_vertex_map_gl(rgbdslam_ctx *ctx, float *VMap, const floa
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!VMap || !RGBD) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_vertex_map_gl, grid2d(n, m), block2d(), 0, ctx->stream, VMap, RGBD, ctx->calib, n, m);
+    KLAUNCH(ctx, k_vertex_map_gl, grid2d(n, m), block2d(), VMap, RGBD, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -261,14 +261,14 @@ extern "C" int rgbdslam_gpu_add_zbuff_off(rgbdslam_ctx *ctx, const uint16_t *dep
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!depth || !rgb_in || !RGBD || pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    hipLaunchKernelGGL(k_add_zbuff_off, grid2d(n, m), block2d(), 0, ctx->stream, depth, pitch, rgb_in, RGBD, ctx->calib, n, m);
+    KLAUNCH(ctx, k_add_zbuff_off, grid2d(n, m), block2d(), depth, pitch, rgb_in, RGBD, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 extern "C" int rgbdslam_init_mask(rgbdslam_ctx *ctx, uint8_t *mask, const float *RGBD, int n, int m) {
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!mask || !RGBD) return RGBDSLAM_E_ARG;
-    hipLaunchKernelGGL(k_init_mask, grid2d(n, m), block2d(), 0, ctx->stream, mask, RGBD, n, m);
+    KLAUNCH(ctx, k_init_mask, grid2d(n, m), block2d(), mask, RGBD, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }

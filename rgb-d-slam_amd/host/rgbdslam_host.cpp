@@ -1,0 +1,699 @@
+// rgbdslam_host.cpp -- C++ host mirror of the reference's L3/L4 classes (see rgbdslam_host.hpp).
+// No kernels here: all device work goes through the C ABI of include/rgbdslam.h.
+#include "rgbdslam_host.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace slam {
+
+void check(int rc, const char *what) {
+    if (rc != 0) throw Error(what, rc);
+}
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e), -(int)e);
+}
+
+// ---- small dense algebra (Eigen stand-ins; same operation order as the oracle's) ----------------
+Mat3 Mat3::Identity() {
+    Mat3 r;
+    for (int k = 0; k < 9; k++) r.a[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    return r;
+}
+Mat3 Mat3::operator*(const Mat3 &b) const {
+    Mat3 r;
+    for (int c = 0; c < 3; c++)
+        for (int i = 0; i < 3; i++)
+            r.a[c * 3 + i] = ((*this)(i, 0) * b(0, c) + (*this)(i, 1) * b(1, c)) + (*this)(i, 2) * b(2, c);
+    return r;
+}
+Mat3 Mat3::inverse() const {
+    const Mat3 &m = *this;
+    float cof[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            cof[i][j] = m(i1, j1) * m(i2, j2) - m(i1, j2) * m(i2, j1);
+        }
+    float det = (cof[0][0] * m(0, 0) + cof[1][0] * m(1, 0)) + cof[2][0] * m(2, 0);
+    float invdet = 1.0f / det;
+    Mat3 o;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) o(i, j) = cof[j][i] * invdet;
+    return o;
+}
+Mat3 Mat3::neg() const {
+    Mat3 r;
+    for (int k = 0; k < 9; k++) r.a[k] = -a[k];
+    return r;
+}
+float Vec3::norm() const { return sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+Vec3 operator*(const Mat3 &m, const Vec3 &x) {
+    Vec3 r;
+    for (int i = 0; i < 3; i++) r.v[i] = (m(i, 0) * x.v[0] + m(i, 1) * x.v[1]) + m(i, 2) * x.v[2];
+    return r;
+}
+float norm_minus_identity(const Mat3 &m) {
+    float s = 0.0f;
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) {
+            float v = m(r, c) - (r == c ? 1.0f : 0.0f);
+            s = s + v * v;
+        }
+    return sqrtf(s);
+}
+
+void quaternion2matrix(double *q, double m[3][3]) {   // D1/Utilities.cpp:1145-1167
+    double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+    double q03 = q[0] * q[3], q13 = q[1] * q[3], q23 = q[2] * q[3];
+    double q02 = q[0] * q[2], q12 = q[1] * q[2], q01 = q[0] * q[1];
+    m[0][0] = q00 + q11 - q22 - q33;
+    m[1][1] = q00 - q11 + q22 - q33;
+    m[2][2] = q00 - q11 - q22 + q33;
+    m[0][1] = 2.0 * (q12 - q03);
+    m[1][0] = 2.0 * (q12 + q03);
+    m[0][2] = 2.0 * (q13 + q02);
+    m[2][0] = 2.0 * (q13 - q02);
+    m[1][2] = 2.0 * (q23 - q01);
+    m[2][1] = 2.0 * (q23 + q01);
+}
+
+void pack_pose(const Mat3 &R, const Vec3 &t, float *P) {   // D1/GP-demo.cpp:206-211
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) P[j * 4 + i] = R(i, j);
+    for (int i = 0; i < 3; i++) P[12 + i] = t(i);
+    P[3] = 0.0f; P[7] = 0.0f; P[11] = 0.0f; P[15] = 1.0f;
+}
+
+float det6(const float *Ain) {
+    float a[36];
+    memcpy(a, Ain, sizeof(a));
+    float det = 1.0f;
+    for (int c = 0; c < 6; c++) {
+        int p = c;
+        float best = fabsf(a[c * 6 + c]);
+        for (int r = c + 1; r < 6; r++) {
+            float v = fabsf(a[r * 6 + c]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (p != c) {
+            for (int k = 0; k < 6; k++) { float tmp = a[c * 6 + k]; a[c * 6 + k] = a[p * 6 + k]; a[p * 6 + k] = tmp; }
+            det = -det;
+        }
+        float piv = a[c * 6 + c];
+        det = det * piv;
+        if (piv == 0.0f || piv != piv) return det;
+        for (int r = c + 1; r < 6; r++) {
+            float f = a[r * 6 + c] / piv;
+            for (int k = c + 1; k < 6; k++) a[r * 6 + k] = a[r * 6 + k] - f * a[c * 6 + k];
+        }
+    }
+    return det;
+}
+
+bool llt_solve6(const float *A, const float *b, float *x) {
+    float L[36];
+    memset(L, 0, sizeof(L));
+    for (int k = 0; k < 6; k++) {
+        float s = A[k * 6 + k];
+        for (int p = 0; p < k; p++) s = s - L[k * 6 + p] * L[k * 6 + p];
+        if (!(s > 0.0f)) return false;
+        float lkk = sqrtf(s);
+        L[k * 6 + k] = lkk;
+        for (int r = k + 1; r < 6; r++) {
+            float v = A[r * 6 + k];
+            for (int p = 0; p < k; p++) v = v - L[r * 6 + p] * L[k * 6 + p];
+            L[r * 6 + k] = v / lkk;
+        }
+    }
+    float y[6];
+    for (int r = 0; r < 6; r++) {
+        float v = b[r];
+        for (int p = 0; p < r; p++) v = v - L[r * 6 + p] * y[p];
+        y[r] = v / L[r * 6 + r];
+    }
+    for (int r = 5; r >= 0; r--) {
+        float v = y[r];
+        for (int p = r + 1; p < 6; p++) v = v - L[p * 6 + r] * x[p];
+        x[r] = v / L[r * 6 + r];
+    }
+    return true;
+}
+
+// ---- device buffers -----------------------------------------------------------------------------
+template <typename T>
+void DevBuf<T>::alloc(size_t n, bool zero) {
+    release();
+    hip_check(hipMalloc((void **)&p, n * sizeof(T)), "hipMalloc");
+    count = n;
+    if (zero) hip_check(hipMemset(p, 0, n * sizeof(T)), "hipMemset");
+}
+template <typename T>
+void DevBuf<T>::release() {
+    if (p) { (void)hipFree(p); p = nullptr; count = 0; }
+}
+template struct DevBuf<float>;
+template struct DevBuf<uint8_t>;
+template struct DevBuf<uint16_t>;
+template struct DevBuf<uint32_t>;
+template struct DevBuf<uint64_t>;
+template struct DevBuf<int32_t>;
+template struct DevBuf<void *>;
+
+static hipStream_t ctx_stream(rgbdslam_ctx *ctx) {
+    void *s = nullptr;
+    check(rgbdslam_get_stream(ctx, &s), "rgbdslam_get_stream");
+    return (hipStream_t)s;
+}
+
+// ---- InputFrame / OffLineFrame (D1/Frame.h:19-134, D1/Frame.cpp:43-77) ----------------------------
+InputFrame::InputFrame(rgbdslam_ctx *ctx, int n, int m) : _ctx(ctx), _n(n), _m(m) {
+    size_t P = (size_t)n * m;
+    _VMap_dev.alloc(3 * P);
+    _NMap_dev.alloc(3 * P);
+    _RGB_dev.alloc(3 * P);
+}
+
+OffLineFrame::OffLineFrame(rgbdslam_ctx *ctx, int n, int m) : InputFrame(ctx, n, m) {
+    _depth_dev_test.alloc((size_t)n * m);
+    _color_dev_test.alloc(3 * (size_t)n * m);
+}
+
+void OffLineFrame::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
+    size_t P = (size_t)_n * _m;
+    hipStream_t s = ctx_stream(_ctx);
+    // GpuMat::upload x2 (Frame.cpp:56-60)
+    hip_check(hipMemcpyAsync(_depth_dev_test.p, depth_host, 2 * P, hipMemcpyHostToDevice, s), "upload depth");
+    hip_check(hipMemcpyAsync(_color_dev_test.p, bgr_host, 3 * P, hipMemcpyHostToDevice, s), "upload colour");
+    _depth_cur = _depth_dev_test.p;
+    _depth_pitch = 2 * (size_t)_m;
+    preprocess(_color_dev_test.p, 3 * (size_t)_m);
+}
+
+void OffLineFrame::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    _depth_cur = depth_dev;
+    _depth_pitch = depth_pitch;
+    preprocess(bgr_dev, bgr_pitch);
+}
+
+void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
+    check(rgbdslam_gpu_cpy_char3(_ctx, bgr, bgr_pitch, _RGB_dev.p, _n, _m), "gpu_cpy_char3");            // Frame.cpp:65
+    check(rgbdslam_vertex_map_kinect(_ctx, _VMap_dev.p, _depth_cur, _depth_pitch, _n, _m), "VertexMapKinect");  // :68
+    check(rgbdslam_compute_normal(_ctx, _NMap_dev.p, _VMap_dev.p, _n, _m, 1), "ComputeNormal");           // :71
+}
+
+// ---- PredictedFrame (D1/Frame.h:188-282) -----------------------------------------------------------
+PredictedFrame::PredictedFrame(rgbdslam_ctx *ctx, int n, int m) : _n(n), _m(m), _ctx(ctx) {
+    size_t P = (size_t)n * m;
+    _VMap_dev.alloc(3 * P);
+    _NMap_dev.alloc(3 * P);
+    _RGB_dev.alloc(4 * P);
+    _tex.alloc(4 * P);
+    _mask_a.alloc(P); _mask_b.alloc(P); _label_a.alloc(P); _label_b.alloc(P);
+    _Mask_dev = _mask_a.p; _Mask_dev_swap = _mask_b.p;
+    _Label_dev = _label_a.p; _Label_dev_swap = _label_b.p;
+    _Index_dev.alloc(4 * (size_t)(n - 1) * (m - 1));
+    _zbuf.alloc(P, false);
+    check(rgbdslam_raster_clear(ctx, _zbuf.p, n, m), "raster_clear");
+}
+
+void PredictedFrame::Transform(float *pose, bool quad) {
+    check(rgbdslam_set_pose_matrix(_ctx, pose), "SetPoseMatrix");                                           // Frame.cpp:283
+    check(rgbdslam_transform_vertex_map(_ctx, _VMap_dev.p, _RGB_dev.p, _n, _m), "TransformVertexMap");      // :290
+    if (quad && use_index_buffer)
+        check(rgbdslam_quad_trim_frame(_ctx, _VMap_dev.p, _Index_dev.p, _n, _m, 0.1f), "QuadTrimFrame");    // :293
+}
+
+void PredictedFrame::ReadFrame(float znear, float zfar) {
+    // DisplayPredictedFBO (GP-demo.cpp:98-113): the GL_QUADS draw becomes the compute rasteriser;
+    // without an index buffer the quads are trimmed inline (same 0.1 threshold, Frame.cpp:293)
+    check(rgbdslam_predict_raster(_ctx, _tex.p, _zbuf.p, _VMap_dev.p, _RGB_dev.p, use_index_buffer ? _Index_dev.p : nullptr,
+                                  0.1f, znear, zfar, _n, _m), "predict_raster");
+    check(rgbdslam_read_frame(_ctx, _VMap_dev.p, _RGB_dev.p, _tex.p, _n, _m), "ReadFrame_cu");              // Frame.cpp:239
+    // the cudaMemset of NMap (Frame.cpp:241) is dropped: compute_normal writes every pixel
+    check(rgbdslam_compute_normal(_ctx, _NMap_dev.p, _VMap_dev.p, _n, _m, 1), "ComputeNormal");             // :242
+}
+
+void PredictedFrame::Merge(OffLineFrame *frame) {
+    check(rgbdslam_merge_depth_off(_ctx, _RGB_dev.p, frame->depth(), frame->depth_pitch(), frame->getRGB(), _Mask_dev, _n, _m),
+          "MergeDepthOff");                                                                                 // Frame.cpp:313
+    // the two cudaMemsets (Frame.cpp:317-318) are dropped: both kernels below write every pixel
+    check(rgbdslam_vertex_map_gl(_ctx, _VMap_dev.p, _RGB_dev.p, _n, _m), "VertexMapGL");                    // :319
+    check(rgbdslam_compute_normal(_ctx, _NMap_dev.p, _VMap_dev.p, _n, _m, 1), "ComputeNormal");             // :320
+}
+
+void PredictedFrame::Cpy(OffLineFrame *frame) {
+    size_t P = (size_t)_n * _m;
+    hipStream_t s = ctx_stream(_ctx);
+    hip_check(hipMemcpyAsync(_VMap_dev.p, frame->getVMap(), 12 * P, hipMemcpyDeviceToDevice, s), "Cpy VMap");   // Frame.cpp:346
+    hip_check(hipMemcpyAsync(_NMap_dev.p, frame->getNMap(), 12 * P, hipMemcpyDeviceToDevice, s), "Cpy NMap");   // :347
+    check(rgbdslam_gpu_add_zbuff_off(_ctx, frame->depth(), frame->depth_pitch(), frame->getRGB(), _RGB_dev.p, _n, _m),
+          "gpu_add_zbuffOff");                                                                              // :351
+}
+
+void PredictedFrame::InitMask() {
+    check(rgbdslam_init_mask(_ctx, _Mask_dev, _RGB_dev.p, _n, _m), "InitMask_cu");                          // Frame.cpp:367
+}
+
+void PredictedFrame::ProjectMask(float *pose) {
+    check(rgbdslam_set_pose_matrix(_ctx, pose), "SetPoseMatrix");
+    check(rgbdslam_project_mask(_ctx, _Mask_dev, _Mask_dev_swap, _VMap_dev.p, _n, _m), "ProjectMask_cu");   // Frame.cpp:376
+    uint8_t *tmp = _Mask_dev; _Mask_dev = _Mask_dev_swap; _Mask_dev_swap = tmp;
+}
+
+void PredictedFrame::ProjectLabel(float *pose_loc, float *pose_glob, float *Equations_dev, int nbPlans) {
+    check(rgbdslam_set_pose_matrix(_ctx, pose_loc), "SetPoseMatrix");
+    check(rgbdslam_project_mask(_ctx, _Label_dev, _Label_dev_swap, _VMap_dev.p, _n, _m), "ProjectMask_cu"); // Frame.cpp:389
+    uint8_t *tmp = _Label_dev; _Label_dev = _Label_dev_swap; _Label_dev_swap = tmp;
+    // Segment_cu with nbPlans == 0 launches kernels that can never relabel anything (no labels
+    // exist before the first detection); skipped.
+    if (nbPlans > 0)
+        check(rgbdslam_segment(_ctx, _Label_dev, _Label_dev_swap, _VMap_dev.p, _NMap_dev.p, pose_glob, Equations_dev, nbPlans,
+                               0.1f, 0.9f, _n, _m), "Segment_cu");                                          // Frame.cpp:395
+}
+
+// ---- Primitive (D1/Primitive.h:79-112,165-190) --------------------------------------------------------
+Primitive::Primitive(float *nmle, float *e1, float *e2, float dist, float *scale, int *Size, float *Shift, float *anchor) {
+    for (int k = 0; k < 3; k++) { _nmle[k] = nmle[k]; _e1[k] = e1[k]; _e2[k] = e2[k]; _anchor[k] = anchor[k]; }
+    _dist = dist;
+    for (int k = 0; k < 2; k++) { _scale[k] = scale[k]; _Size[k] = Size[k]; _Shift[k] = Shift[k]; }
+}
+void Primitive::Allocate() { _param_dev.alloc(14); }
+void Primitive::SetParam() {
+    float tmp[14];
+    tmp[0] = _nmle[0]; tmp[1] = _nmle[1]; tmp[2] = _nmle[2]; tmp[3] = _dist;
+    tmp[4] = _scale[0]; tmp[5] = _scale[1];
+    tmp[6] = _Shift[0]; tmp[7] = _Shift[1];
+    tmp[8] = _e1[0]; tmp[9] = _e1[1]; tmp[10] = _e1[2];
+    tmp[11] = _e2[0]; tmp[12] = _e2[1]; tmp[13] = _e2[2];
+    hip_check(hipMemcpy(_param_dev.p, tmp, sizeof(tmp), hipMemcpyHostToDevice), "SetParam");
+}
+
+// ---- Graph (D1/Graph.h:54-116, D1/Graph.cpp:50-95) ----------------------------------------------------
+Graph::Graph(rgbdslam_ctx *ctx, int frag_n, int frag_m, int max_planes) : _ctx(ctx), _max_planes(max_planes) {
+    _SizeVBUFF[0] = frag_n;
+    _SizeVBUFF[1] = frag_m;
+}
+Graph::~Graph() {
+    Clear();
+    for (auto *b : _data_Bump_dev) delete b;
+    for (auto *b : _data_RGB_dev) delete b;
+    for (auto *b : _data_Mask_dev) delete b;
+    for (auto *b : _data_Claim_dev) delete b;
+}
+void Graph::Clear() {
+    for (Primitive *p : _nodes) delete p;
+    _nodes.clear();
+    _tables_built = false;
+}
+bool Graph::AddPrimitive(Primitive *Prim) {
+    size_t idx = _nodes.size();
+    if ((int)idx > _max_planes - 1) return false;                                  // Graph.h:103 (50 in the reference)
+    size_t C = (size_t)_SizeVBUFF[0] * _SizeVBUFF[1];
+    // The reference preallocates all 50 slabs in the constructor (Graph.h:64-72); here slabs are
+    // created on first use so that small test configurations stay small.  Bump/RGB start at zero
+    // (uninitialised cudaMalloc memory in the reference).
+    if (_data_Bump_dev.size() <= idx) {
+        auto *b = new DevBuf<uint16_t>(); b->alloc(3 * C); _data_Bump_dev.push_back(b);
+        auto *r = new DevBuf<uint8_t>(); r->alloc(3 * C); _data_RGB_dev.push_back(r);
+        auto *k = new DevBuf<uint8_t>(); k->alloc(C); _data_Mask_dev.push_back(k);
+        auto *c = new DevBuf<uint64_t>(); c->alloc(C); _data_Claim_dev.push_back(c);
+    } else {
+        hip_check(hipMemset(_data_Bump_dev[idx]->p, 0, 6 * C), "memset bump");
+        hip_check(hipMemset(_data_RGB_dev[idx]->p, 0, 3 * C), "memset rgb");
+    }
+    Prim->_Bump_dev = _data_Bump_dev[idx]->p;
+    Prim->_RGB_dev = _data_RGB_dev[idx]->p;
+    Prim->_Mask_dev = _data_Mask_dev[idx]->p;
+    Prim->_Claim_dev = _data_Claim_dev[idx]->p;
+    hip_check(hipMemset(Prim->_Mask_dev, 0, C), "memset mask");                    // Graph.h:112
+    _nodes.push_back(Prim);
+    _tables_built = false;
+    return true;
+}
+void Graph::Update(PredictedFrame *frame, float *pose) {
+    size_t S = _nodes.size();
+    if (S == 0) return;                                                            // Graph.cpp:53-54
+    if (!_tables_built) {                                                          // Graph.cpp:56-70
+        std::vector<void *> bt(S), rt(S), mt(S), pt(S), ct(S);
+        for (size_t i = 0; i < S; i++) {
+            Primitive *Prim = _nodes[i];
+            Prim->SetParam();
+            bt[i] = Prim->_Bump_dev; rt[i] = Prim->_RGB_dev; mt[i] = Prim->_Mask_dev; pt[i] = Prim->_param_dev.p;
+            ct[i] = Prim->_Claim_dev;
+        }
+        // one H2D copy per table replaces the 1-thread Affect* kernels (D1/RG.cu:557-567)
+        DevBuf<void *> *tabs[5] = {&_BumpTab, &_RGBTab, &_MaskTab, &_ParamTab, &_ClaimTab};
+        std::vector<void *> *src[5] = {&bt, &rt, &mt, &pt, &ct};
+        for (int k = 0; k < 5; k++) {
+            tabs[k]->alloc(S, false);
+            hip_check(hipMemcpy(tabs[k]->p, src[k]->data(), S * sizeof(void *), hipMemcpyHostToDevice), "pointer table");
+        }
+        _tables_built = true;
+    }
+    _stamp++;
+    check(rgbdslam_update(_ctx, (uint16_t **)_BumpTab.p, (uint8_t **)_RGBTab.p, (uint8_t **)_MaskTab.p, (float **)_ParamTab.p,
+                          (uint64_t **)_ClaimTab.p, _stamp, frame->getVMap(), frame->getRGB(), frame->_Mask_dev,
+                          frame->_Label_dev, pose, _SizeVBUFF[0], _SizeVBUFF[1], frame->_n, frame->_m, plane_lo, plane_hi),
+          "Update_cu");                                                            // Graph.cpp:74
+}
+
+// ---- RG (D1/RG.h:111-250, D1/RG.cpp) -------------------------------------------------------------------
+RG::RG(int device, void *stream, int n, int m, const float *Calib, int lvl, float distThres, float angleThres, int max_planes,
+       int N_prim, int M_prim)
+    : _count(1), _nbPlan(0), _lvl(lvl), _distThres(distThres), _angleThres(angleThres), _thres_cvg_alpha(1e-6f),
+      _thres_cvg_tr(1e-6f) {
+    check(rgbdslam_create(&_ctx, device, stream), "rgbdslam_create");
+    memcpy(_calib, Calib, sizeof(_calib));
+    check(rgbdslam_set_calibration_matrix(_ctx, _calib), "SetCalibrationMatrix");   // RG.h:186
+    int gr = ((n % 8) ? (n + 7) / 8 : n / 8), gc = ((m % 8) ? (m + 7) / 8 : m / 8);
+    check(rgbdslam_alloc_buffers(_ctx, gr, gc), "AllocBuffers");                     // RG.h:189
+    _max_iter[0] = 3; _max_iter[1] = 2; _max_iter[2] = 1;                           // RG.h:124-126
+    _poseR = _poseRPrev = Mat3::Identity();
+    _poset = _posetPrev = Vec3::Zero();
+    _frame = new OffLineFrame(_ctx, n, m);
+    _predicted_frame = new PredictedFrame(_ctx, n, m);
+    _graph = new Graph(_ctx, N_prim, M_prim, max_planes);
+    size_t P = (size_t)n * m;
+    _intr_dev.alloc(4); _Rcurr_dev.alloc(9); _tcurr_dev.alloc(3);
+    hip_check(hipMemcpy(_intr_dev.p, _calib, 16, hipMemcpyHostToDevice), "intr");   // RG.h:200-204
+    _img1.alloc(P); _Gx.alloc(P); _Gy.alloc(P);
+    _pose_state_dev.alloc(24); _status_dev.alloc(4); _trace_dev.alloc(33 * 16);
+    hip_check(hipHostMalloc((void **)&_pinned, 32 * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+}
+
+RG::~RG() {
+    if (_ctx) (void)rgbdslam_synchronize(_ctx);
+    delete _graph;
+    delete _predicted_frame;
+    delete _frame;
+    if (_pinned) (void)hipHostFree(_pinned);
+    _intr_dev.release(); _Rcurr_dev.release(); _tcurr_dev.release(); _img1.release(); _Gx.release(); _Gy.release();
+    _pose_state_dev.release(); _status_dev.release(); _trace_dev.release(); _Equations_dev.release();
+    if (_ctx) (void)rgbdslam_destroy(_ctx);
+}
+
+bool RG::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
+    _frame->LoadFrame(depth_host, bgr_host);                                        // RG.cpp:141
+    _count++;                                                                       // RG.cpp:144
+    return true;
+}
+bool RG::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    _frame->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
+    _count++;
+    return true;
+}
+
+bool RG::AlignFrameGaussNewton() {
+    int n = _frame->getN(), m = _frame->getM();
+    size_t pitch = 4 * (size_t)m;
+    hipStream_t s = ctx_stream(_ctx);
+    // gpu_cpy + 2 x cv::gpu::Sobel, fused (RG.cpp:807-810)
+    check(rgbdslam_intensity_sobel(_ctx, _frame->getRGB(), nullptr, 0, _Gx.p, pitch, _Gy.p, pitch, n, m), "intensity_sobel");
+    float *VMap_prev = _predicted_frame->getVMap(), *NMap_prev = _predicted_frame->getNMap();
+    float *VMap = _frame->getVMap(), *NMap = _frame->getNMap();
+
+    if (device_loop) {
+        // the whole loop of RG.cpp:832-926 on the device; one host sync for the result
+        float *ps = _pinned;
+        memcpy(ps, _poseR.a, 36); memcpy(ps + 9, _poset.v, 12); memcpy(ps + 12, _poseRPrev.a, 36); memcpy(ps + 21, _posetPrev.v, 12);
+        hip_check(hipMemcpyAsync(_pose_state_dev.p, ps, 96, hipMemcpyHostToDevice, s), "pose upload");
+        rgbdslam_icp_params prm;
+        prm.lvl = _lvl;
+        for (int k = 0; k < 3; k++) prm.max_iter[k] = _max_iter[k];
+        prm.distThres = _distThres; prm.angleThres = _angleThres;
+        prm.thres_cvg_alpha = _thres_cvg_alpha; prm.thres_cvg_tr = _thres_cvg_tr;
+        check(rgbdslam_align_gauss_newton(_ctx, &prm, VMap, NMap, _frame->getRGB(), _Gx.p, pitch, _Gy.p, pitch, VMap_prev,
+                                          NMap_prev, _predicted_frame->getRGB(), n, m, _pose_state_dev.p, _status_dev.p, nullptr),
+              "align_gauss_newton");
+        hip_check(hipMemcpyAsync(ps, _pose_state_dev.p, 48, hipMemcpyDeviceToHost, s), "pose download");
+        hip_check(hipMemcpyAsync(ps + 24, _status_dev.p, 16, hipMemcpyDeviceToHost, s), "status download");
+        hip_check(hipStreamSynchronize(s), "sync");
+        const int32_t *st = (const int32_t *)(ps + 24);
+        last_iterations = st[1];
+        last_level_iterations = st[2];
+        if (!st[0]) return false;
+        memcpy(_poseR.a, ps, 36); memcpy(_poset.v, ps + 9, 12);
+        return true;
+    }
+
+    // per-iteration host loop, statement for statement (RG.cpp:823-926)
+    Mat3 Rcurr = _poseR;
+    Vec3 tcurr = _poset;
+    int fact = 1 << (_lvl - 1);                                                     // RG.cpp:832
+    Mat3 Rcurr_inv = Rcurr.inverse();
+    Vec3 tcurr_inv = Rcurr_inv.neg() * tcurr;
+    last_iterations = 0;
+    for (int lvl = _lvl - 1; lvl > -1; lvl--) {
+        float A[36], b[6], x[6];
+        bool cvg = false;
+        int iter = 0;
+        while (!cvg) {
+            Rcurr = Rcurr_inv * _poseRPrev;                                         // RG.cpp:851
+            tcurr = Rcurr_inv * _posetPrev + tcurr_inv;
+            hip_check(hipMemcpyAsync(_Rcurr_dev.p, Rcurr.a, 36, hipMemcpyHostToDevice, s), "Rcurr");
+            hip_check(hipMemcpyAsync(_tcurr_dev.p, tcurr.v, 12, hipMemcpyHostToDevice, s), "tcurr");
+            check(rgbdslam_estimate_system_gauss_newton(_ctx, _Rcurr_dev.p, _tcurr_dev.p, VMap, NMap, _frame->getRGB(), _Gx.p,
+                                                        pitch, _Gy.p, pitch, VMap_prev, NMap_prev, _predicted_frame->getRGB(),
+                                                        _intr_dev.p, _distThres, _angleThres, n, m, A, b, fact, nullptr),
+                  "EstimateSystemGaussNewton");                                     // RG.cpp:858
+            last_iterations++;
+            float det = det6(A);                                                    // RG.cpp:862
+            if (fabsf(det) < 1e-15 || det != det) return false;
+            if (!llt_solve6(A, b, x)) return false;                                 // RG.cpp:873
+            double q[4];
+            double norm = (double)((x[3] * x[3] + x[4] * x[4]) + x[5] * x[5]);
+            q[1] = x[3]; q[2] = x[4]; q[3] = x[5]; q[0] = sqrt(1 - norm);
+            double tmp[3][3];
+            quaternion2matrix(q, tmp);
+            Mat3 Rinc;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) Rinc(r, c) = (float)tmp[r][c];
+            Vec3 tinc{{x[0], x[1], x[2]}};
+            tcurr_inv = Rinc * tcurr_inv + tinc;                                    // RG.cpp:886
+            Rcurr_inv = Rinc * Rcurr_inv;
+            if (iter > _max_iter[lvl] || (norm_minus_identity(Rinc) < _thres_cvg_alpha && tinc.norm() < _thres_cvg_tr)) cvg = true;
+            iter++;
+        }
+        fact /= 2;
+    }
+    if (norm_minus_identity(Rcurr) > 0.3 || tcurr.norm() > 0.3) return false;       // RG.cpp:910
+    Rcurr = Rcurr_inv.inverse();                                                    // RG.cpp:923
+    tcurr = Rcurr.neg() * tcurr_inv;
+    _poseR = Rcurr;
+    _poset = tcurr;
+    return true;
+}
+
+void RG::SetPlanes(const float *equations, const float *centers, int nbPlan) {
+    _graph->Clear();
+    _Equations.assign(equations, equations + 10 * (size_t)nbPlan);
+    _Centers.assign(centers, centers + 3 * (size_t)nbPlan);
+    _nbPlan = nbPlan;
+    float pose[16];
+    pack_pose(_poseR, _poset, pose);
+    CreatePrimitives(pose);
+}
+
+void RG::CreatePrimitives(float *pose) {
+    std::vector<int> Assoc(_nbPlan, -1);
+    int count = 0;
+    for (int i = 0; i < _nbPlan; i++) {
+        float scale[2] = {(float)(2.0 / RES_PLANE), (float)(2.0 / RES_PLANE)};       // RG.cpp:706
+        int Size_frag[2] = {_graph->_SizeVBUFF[0], _graph->_SizeVBUFF[1]};
+        float center[2], pt[2];
+        const float *E = &_Equations[10 * i], *Cn = &_Centers[3 * i];
+        pt[0] = (Cn[0] * E[3] + Cn[1] * E[4]) + Cn[2] * E[5];                        // RG.cpp:717-718
+        pt[1] = (Cn[0] * E[6] + Cn[1] * E[7]) + Cn[2] * E[8];
+        center[0] = (float)((double)pt[0] - ((double)(float)Size_frag[0] * RES_PLANE) / 2.0);   // RG.cpp:720-721
+        center[1] = (float)((double)pt[1] - ((double)(float)Size_frag[1] * RES_PLANE) / 2.0);
+        Primitive *ThePrim = new Primitive(&_Equations[10 * i], &_Equations[10 * i + 3], &_Equations[10 * i + 6],
+                                           _Equations[10 * i + 9], scale, Size_frag, center, &_Centers[3 * i]);
+        if (!_graph->AddPrimitive(ThePrim)) { delete ThePrim; continue; }            // RG.cpp:733-737
+        ThePrim->Allocate();
+        Assoc[i] = count++;
+    }
+    std::vector<float> Eq(10 * (size_t)count), Ce(3 * (size_t)count);
+    for (int i = 0; i < _nbPlan; i++)
+        if (Assoc[i] != -1) {
+            memcpy(&Eq[10 * Assoc[i]], &_Equations[10 * i], 40);
+            memcpy(&Ce[3 * Assoc[i]], &_Centers[3 * i], 12);
+        }
+    _Equations.swap(Eq);
+    _Centers.swap(Ce);
+    _nbPlan = count;
+    if (count == 0) return;
+    _Equations_dev.alloc(10 * (size_t)count, false);                                 // RG.cpp:779-780
+    hip_check(hipMemcpy(_Equations_dev.p, _Equations.data(), 40 * (size_t)count, hipMemcpyHostToDevice), "Equations");
+    // The reference grows the labels produced by DetectPrimitives with Segment_cu (RG.cpp:786).
+    // Plane detection is not built yet: labels are seeded by plane membership with
+    // the same thresholds (ACCEPT_THRESH 0.1, 0.8).
+    check(rgbdslam_seed_labels(_ctx, _predicted_frame->_Label_dev, _predicted_frame->getVMap(), _predicted_frame->getNMap(), pose,
+                               _Equations_dev.p, _nbPlan, 0.1f, 0.8f, _predicted_frame->_n, _predicted_frame->_m), "seed_labels");
+}
+
+int RG::Step() {
+    float pose[16], pose_inv[16];
+    bool first = false;
+    if (_count == 2) {                                                              // GP-demo.cpp:164-167
+        _predicted_frame->Cpy(_frame);
+        _predicted_frame->InitMask();
+        first = true;
+    }
+    if (!AlignFrameGaussNewton()) {                                                 // GP-demo.cpp:189-196
+        _predicted_frame->Cpy(_frame);
+        _predicted_frame->InitMask();
+        _poseRPrev = _poseR;
+        _posetPrev = _poset;
+        return 0;
+    }
+    Mat3 poseRinv = _poseR.inverse();                                               // GP-demo.cpp:201-211
+    Vec3 posetinv = poseRinv.neg() * _poset;
+    Mat3 poseR = poseRinv * _poseRPrev;
+    Vec3 poset = poseRinv * _posetPrev + posetinv;
+    pack_pose(poseR, poset, pose_inv);
+    _predicted_frame->Transform(pose_inv, true);                                    // GP-demo.cpp:215
+    _predicted_frame->ReadFrame(Znear, Zfar);                                       // GP-demo.cpp:222-223
+    poseRinv = poseR.inverse();                                                     // GP-demo.cpp:225-236
+    posetinv = poseRinv.neg() * poset;
+    pack_pose(poseRinv, posetinv, pose_inv);
+    pack_pose(_poseR, _poset, pose);
+    _predicted_frame->ProjectMask(pose_inv);                                        // GP-demo.cpp:237
+    _predicted_frame->ProjectLabel(pose_inv, pose, _Equations_dev.p, _nbPlan);      // GP-demo.cpp:238
+    _poseRPrev = _poseR;                                                            // GP-demo.cpp:244-245
+    _posetPrev = _poset;
+    _predicted_frame->Merge(_frame);                                                // GP-demo.cpp:249
+    _graph->Update(_predicted_frame, pose);                                         // GP-demo.cpp:260
+    return first ? 2 : 1;
+}
+
+}  // namespace slam
+
+// =====================================================================================================
+// C facade over the classes (for ctypes drivers: tests, bench.py).  Exceptions become error codes.
+// =====================================================================================================
+using slam::RG;
+
+#define FACADE_TRY(stmt)                                   \
+    try { stmt; }                                          \
+    catch (const slam::Error &e) { g_last_error = e.what(); return e.code ? e.code : -1; } \
+    catch (const std::exception &e) { g_last_error = e.what(); return -1; }
+
+static thread_local std::string g_last_error;
+
+extern "C" {
+
+const char *slamhost_last_error(void) { return g_last_error.c_str(); }
+
+int slamhost_rg_create(void **out, int device, void *stream, int n, int m, const float *calib11, int lvl, float distThres,
+                       float angleThres, int max_planes, int N_prim, int M_prim) {
+    if (!out || !calib11 || n < 2 || m < 2) return RGBDSLAM_E_ARG;
+    FACADE_TRY(*out = new RG(device, stream, n, m, calib11, lvl, distThres, angleThres, max_planes, N_prim, M_prim));
+    return 0;
+}
+int slamhost_rg_destroy(void *rg) {
+    delete (RG *)rg;
+    return 0;
+}
+int slamhost_rg_set_device_loop(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    ((RG *)rg)->device_loop = on != 0;
+    return 0;
+}
+int slamhost_rg_set_index_buffer(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    ((RG *)rg)->_predicted_frame->use_index_buffer = on != 0;
+    return 0;
+}
+int slamhost_rg_set_plane_range(void *rg, int lo, int hi) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    ((RG *)rg)->_graph->plane_lo = lo;
+    ((RG *)rg)->_graph->plane_hi = hi;
+    return 0;
+}
+int slamhost_rg_load_frame(void *rg, const uint16_t *depth_host, const uint8_t *bgr_host) {
+    if (!rg || !depth_host || !bgr_host) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->LoadFrame(depth_host, bgr_host));
+    return 0;
+}
+int slamhost_rg_load_frame_device(void *rg, const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    if (!rg || !depth_dev || !bgr_dev) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch));
+    return 0;
+}
+int slamhost_rg_set_planes(void *rg, const float *equations, const float *centers, int nb) {
+    if (!rg || !equations || !centers || nb <= 0) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SetPlanes(equations, centers, nb));
+    return 0;
+}
+// *status: 2 = model seeded, 1 = tracked, 0 = lost (model re-seeded)
+int slamhost_rg_step(void *rg, int *status) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    int st = 0;
+    FACADE_TRY(st = ((RG *)rg)->Step());
+    if (status) *status = st;
+    return 0;
+}
+// Runs `count` display() passes over device-resident frames (depth_dev[k], bgr_dev[k]); returns
+// the number of tracked frames in *tracked.  One host sync per frame (the pose read), no other.
+int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, const uint8_t *const *bgr_dev, int count,
+                                    size_t depth_pitch, size_t bgr_pitch, int *tracked) {
+    if (!rg || !depth_dev || !bgr_dev || count < 0) return RGBDSLAM_E_ARG;
+    int ok = 0;
+    FACADE_TRY(for (int k = 0; k < count; k++) {
+        ((RG *)rg)->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
+        if (((RG *)rg)->Step() != 0) ok++;
+    });
+    if (tracked) *tracked = ok;
+    return 0;
+}
+int slamhost_rg_synchronize(void *rg) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    return rgbdslam_synchronize(((RG *)rg)->ctx());
+}
+int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {
+    if (!rg || !R9_cm || !t3) return RGBDSLAM_E_ARG;
+    memcpy(R9_cm, ((RG *)rg)->_poseR.a, 36);
+    memcpy(t3, ((RG *)rg)->_poset.v, 12);
+    return 0;
+}
+int slamhost_copy_to_host(void *dst_host, const void *src_dev, size_t bytes) {
+    if (!dst_host || !src_dev) return RGBDSLAM_E_ARG;
+    hipError_t e = hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+int slamhost_rg_last_iterations(void *rg) { return rg ? ((RG *)rg)->last_iterations : -1; }
+int slamhost_rg_last_level_iterations(void *rg) { return rg ? ((RG *)rg)->last_level_iterations : -1; }
+void *slamhost_rg_ctx(void *rg) { return rg ? (void *)((RG *)rg)->ctx() : nullptr; }
+int slamhost_rg_count(void *rg) { return rg ? ((RG *)rg)->_count : -1; }
+// Device address + size of a named buffer: VMap NMap RGBD Mask Label frame.VMap frame.NMap
+// frame.RGB Bump<k> RGBb<k> Maskb<k>
+int slamhost_rg_buffer(void *rgp, const char *name, void **ptr, size_t *bytes) {
+    if (!rgp || !name || !ptr || !bytes) return RGBDSLAM_E_ARG;
+    RG *rg = (RG *)rgp;
+    slam::PredictedFrame *pf = rg->_predicted_frame;
+    size_t P = (size_t)pf->_n * pf->_m, C = (size_t)rg->_graph->_SizeVBUFF[0] * rg->_graph->_SizeVBUFF[1];
+    *ptr = nullptr; *bytes = 0;
+    std::string s(name);
+    if (s == "VMap") { *ptr = pf->getVMap(); *bytes = 12 * P; }
+    else if (s == "NMap") { *ptr = pf->getNMap(); *bytes = 12 * P; }
+    else if (s == "RGBD") { *ptr = pf->getRGB(); *bytes = 16 * P; }
+    else if (s == "Mask") { *ptr = pf->_Mask_dev; *bytes = P; }
+    else if (s == "Label") { *ptr = pf->_Label_dev; *bytes = P; }
+    else if (s == "frame.VMap") { *ptr = rg->_frame->getVMap(); *bytes = 12 * P; }
+    else if (s == "frame.NMap") { *ptr = rg->_frame->getNMap(); *bytes = 12 * P; }
+    else if (s == "frame.RGB") { *ptr = rg->_frame->getRGB(); *bytes = 12 * P; }
+    else {
+        auto plane = [&](size_t off) -> slam::Primitive * {
+            int k = atoi(name + off);
+            return (k >= 0 && (size_t)k < rg->_graph->_nodes.size()) ? rg->_graph->_nodes[k] : nullptr;
+        };
+        if (s.rfind("Bump", 0) == 0) { if (auto *p = plane(4)) { *ptr = p->_Bump_dev; *bytes = 6 * C; } }
+        else if (s.rfind("RGBb", 0) == 0) { if (auto *p = plane(4)) { *ptr = p->_RGB_dev; *bytes = 3 * C; } }
+        else if (s.rfind("Maskb", 0) == 0) { if (auto *p = plane(5)) { *ptr = p->_Mask_dev; *bytes = C; } }
+    }
+    return *ptr ? 0 : RGBDSLAM_E_ARG;
+}
+
+}  // extern "C"

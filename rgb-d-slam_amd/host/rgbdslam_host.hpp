@@ -1,0 +1,205 @@
+// rgbdslam_host.hpp -- C++ host mirror of the reference's L3/L4 classes for the hot path:
+//   InputFrame / OffLineFrame / PredictedFrame   (D1/Frame.h, D1/Frame.cpp)
+//   Primitive                                    (D1/Primitive.h)
+//   Graph                                        (D1/Graph.h, D1/Graph.cpp)
+//   RG                                           (D1/RG.h, D1/RG.cpp)  + the display() loop of D1/GP-demo.cpp
+// Same entry-point names and argument meaning; all device work goes through the C ABI of
+// include/rgbdslam.h (no kernels here).  GL/VBO interop, file I/O and the Kinect path are dropped
+// (out of scope).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbdslam.h"
+
+namespace slam {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(const std::string &what, int c) : std::runtime_error(what + " (code " + std::to_string(c) + ")"), code(c) {}
+};
+void check(int rc, const char *what);
+void hip_check(hipError_t e, const char *what);
+
+// 3x3 float, column-major like Eigen::Matrix3f (D1/RG.h:55-58); arithmetic restates the Eigen
+// expressions the reference uses (products left to right, cofactor inverse).
+struct Mat3 {
+    float a[9];
+    float &operator()(int r, int c) { return a[c * 3 + r]; }
+    float operator()(int r, int c) const { return a[c * 3 + r]; }
+    static Mat3 Identity();
+    Mat3 operator*(const Mat3 &b) const;
+    Mat3 inverse() const;
+    Mat3 neg() const;
+};
+struct Vec3 {
+    float v[3];
+    float &operator()(int i) { return v[i]; }
+    float operator()(int i) const { return v[i]; }
+    static Vec3 Zero() { return Vec3{{0.f, 0.f, 0.f}}; }
+    Vec3 operator+(const Vec3 &o) const { return Vec3{{v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]}}; }
+    float norm() const;
+};
+Vec3 operator*(const Mat3 &m, const Vec3 &x);
+float norm_minus_identity(const Mat3 &m);
+// D1/Utilities.cpp:1145-1167
+void quaternion2matrix(double *q, double m[3][3]);
+// 16-float column-major packing used throughout display() (D1/GP-demo.cpp:206-211)
+void pack_pose(const Mat3 &R, const Vec3 &t, float *pose16);
+// Stand-ins for Eigen's 6x6 determinant and LLT (D1/RG.cpp:862,873), parity unpinned.
+float det6(const float *A);
+bool llt_solve6(const float *A, const float *b, float *x);
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    void alloc(size_t n, bool zero = true);
+    void release();
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// ---- D1/Frame.h:19-134 ------------------------------------------------------------------------
+class InputFrame {
+public:
+    InputFrame(rgbdslam_ctx *ctx, int n, int m);
+    virtual ~InputFrame() {}
+    int getN() const { return _n; }
+    int getM() const { return _m; }
+    float *getVMap() { return _VMap_dev.p; }
+    float *getNMap() { return _NMap_dev.p; }
+    float *getRGB() { return _RGB_dev.p; }
+    bool _offline = true;
+protected:
+    rgbdslam_ctx *_ctx;
+    int _n, _m;
+    DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev;
+};
+
+class OffLineFrame : public InputFrame {
+public:
+    OffLineFrame(rgbdslam_ctx *ctx, int n, int m);
+    // D1/Frame.cpp:43-77 with the cv::imread + GpuMat::upload pair replaced by the caller's
+    // decoded images: host buffers (uploaded here) or device-resident ones (used in place).
+    void LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);
+    void LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    const uint16_t *depth() const { return _depth_cur; }
+    size_t depth_pitch() const { return _depth_pitch; }
+private:
+    void preprocess(const uint8_t *bgr, size_t bgr_pitch);
+    DevBuf<uint16_t> _depth_dev_test;
+    DevBuf<uint8_t> _color_dev_test;
+    const uint16_t *_depth_cur = nullptr;
+    size_t _depth_pitch = 0;
+};
+
+// ---- D1/Frame.h:188-282 -----------------------------------------------------------------------
+class PredictedFrame {
+public:
+    PredictedFrame(rgbdslam_ctx *ctx, int n, int m);
+    void Transform(float *pose, bool quad);                       // Frame.cpp:281-298
+    void ReadFrame(float znear, float zfar);                      // GP-demo.cpp:98-113 + Frame.cpp:229-245
+    void Merge(OffLineFrame *frame);                              // Frame.cpp:300-333
+    void Cpy(OffLineFrame *frame);                                // Frame.cpp:335-359
+    void InitMask();                                              // Frame.cpp:361-370
+    void ProjectMask(float *pose);                                // Frame.cpp:372-383
+    void ProjectLabel(float *pose_loc, float *pose_glob, float *Equations_dev, int nbPlans);  // Frame.cpp:385-405
+    float *getVMap() { return _VMap_dev.p; }
+    float *getNMap() { return _NMap_dev.p; }
+    float *getRGB() { return _RGB_dev.p; }
+    int _n, _m;
+    uint8_t *_Mask_dev, *_Mask_dev_swap, *_Label_dev, *_Label_dev_swap;
+    bool use_index_buffer = false;   // true: QuadTrimFrame writes the GL_QUADS index buffer first
+private:
+    rgbdslam_ctx *_ctx;
+    DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev, _tex;
+    DevBuf<uint8_t> _mask_a, _mask_b, _label_a, _label_b;
+    DevBuf<uint32_t> _Index_dev;
+    DevBuf<uint64_t> _zbuf;
+};
+
+// ---- D1/Primitive.h:17-237 (data model of one Bump image) ---------------------------------------
+#define RES_PLANE 0.004
+class Primitive {
+public:
+    Primitive(float *nmle, float *e1, float *e2, float dist, float *scale, int *Size, float *Shift, float *anchor);
+    void Allocate();
+    void SetParam();                                              // Primitive.h:180-190
+    float _nmle[3], _e1[3], _e2[3], _dist, _scale[2], _Shift[2], _anchor[3];
+    int _Size[2];
+    uint8_t *_Mask_dev = nullptr;
+    uint16_t *_Bump_dev = nullptr;
+    uint8_t *_RGB_dev = nullptr;
+    uint64_t *_Claim_dev = nullptr;
+    DevBuf<float> _param_dev;
+};
+
+// ---- D1/Graph.h:17-128 ----------------------------------------------------------------------------
+class Graph {
+public:
+    Graph(rgbdslam_ctx *ctx, int frag_n, int frag_m, int max_planes);
+    ~Graph();
+    bool AddPrimitive(Primitive *Prim);                           // Graph.h:100-116
+    void Update(PredictedFrame *frame, float *pose);              // Graph.cpp:50-95
+    void Clear();
+    std::vector<Primitive *> _nodes;
+    int _SizeVBUFF[2];
+    int plane_lo = 0, plane_hi = 0x7FFFFFFF;                       // plane-partitioned multi-GPU shard
+private:
+    rgbdslam_ctx *_ctx;
+    int _max_planes;
+    std::vector<DevBuf<uint16_t> *> _data_Bump_dev;
+    std::vector<DevBuf<uint8_t> *> _data_RGB_dev, _data_Mask_dev;
+    std::vector<DevBuf<uint64_t> *> _data_Claim_dev;
+    DevBuf<void *> _BumpTab, _RGBTab, _MaskTab, _ParamTab, _ClaimTab;
+    bool _tables_built = false;
+    uint32_t _stamp = 0;
+};
+
+// ---- D1/RG.h:29-330 ---------------------------------------------------------------------------------
+class RG {
+public:
+    // n = height, m = width (RG.h:110-111)
+    RG(int device, void *stream, int n, int m, const float *Calib, int lvl, float distThres, float angleThres,
+       int max_planes = 50, int N_prim = 1024, int M_prim = 1024);
+    ~RG();
+    bool LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);   // RG.cpp:78-147 minus file I/O
+    bool LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    bool AlignFrameGaussNewton();                                  // RG.cpp:797-932
+    // plane injection: stands in for DetectPrimitives then runs CreatePrimitives
+    void SetPlanes(const float *equations, const float *centers, int nbPlan);
+    void CreatePrimitives(float *pose);                            // RG.cpp:699-793
+    // one pass of display() (GP-demo.cpp:138-296): 2 = model seeded, 1 = tracked, 0 = lost
+    int Step();
+
+    OffLineFrame *_frame;
+    PredictedFrame *_predicted_frame;
+    Graph *_graph;
+    Mat3 _poseR, _poseRPrev;
+    Vec3 _poset, _posetPrev;
+    int _count, _nbPlan, _lvl;
+    float _distThres, _angleThres, _thres_cvg_alpha, _thres_cvg_tr;
+    int _max_iter[3];
+    float Znear = 0.5f, Zfar = 10.0f;                              // GP-demo.cpp:18-19
+    bool device_loop = true;   // true: whole Gauss-Newton loop on the GPU; false: per-iteration host solve
+    int last_iterations = 0;
+    int last_level_iterations = 0;   // packed per level, 8 bits each (device loop only)
+    rgbdslam_ctx *ctx() { return _ctx; }
+    std::vector<float> _Equations, _Centers;
+    DevBuf<float> _Equations_dev;
+private:
+    rgbdslam_ctx *_ctx;
+    float _calib[11];
+    DevBuf<float> _intr_dev, _Rcurr_dev, _tcurr_dev, _img1, _Gx, _Gy, _pose_state_dev, _trace_dev;
+    DevBuf<int32_t> _status_dev;
+    float *_pinned = nullptr;   // 24 floats pose state + 4 ints status
+};
+
+}  // namespace slam
