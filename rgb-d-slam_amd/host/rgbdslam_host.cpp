@@ -658,6 +658,28 @@ int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {
     memcpy(t3, ((RG *)rg)->_poset.v, 12);
     return 0;
 }
+// ---- host-logic test hooks (CPU only: no device work) ---------------------------------------------
+void slamhost_test_inverse3(const float *a_cm, float *out_cm) {
+    slam::Mat3 m; memcpy(m.a, a_cm, 36);
+    slam::Mat3 o = m.inverse(); memcpy(out_cm, o.a, 36);
+}
+void slamhost_test_mul3(const float *a_cm, const float *b_cm, float *out_cm) {
+    slam::Mat3 a, b; memcpy(a.a, a_cm, 36); memcpy(b.a, b_cm, 36);
+    slam::Mat3 o = a * b; memcpy(out_cm, o.a, 36);
+}
+float slamhost_test_det6(const float *A) { return slam::det6(A); }
+int slamhost_test_llt_solve6(const float *A, const float *b, float *x) { return slam::llt_solve6(A, b, x) ? 0 : 1; }
+void slamhost_test_quaternion2matrix(const double *q, double *m9_rowmajor) {
+    double qq[4] = {q[0], q[1], q[2], q[3]}, m[3][3];
+    slam::quaternion2matrix(qq, m);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m9_rowmajor[3 * r + c] = m[r][c];
+}
+void slamhost_test_pack_pose(const float *R_cm, const float *t, float *pose16) {
+    slam::Mat3 R; memcpy(R.a, R_cm, 36);
+    slam::Vec3 v{{t[0], t[1], t[2]}};
+    slam::pack_pose(R, v, pose16);
+}
+
 int slamhost_copy_to_host(void *dst_host, const void *src_dev, size_t bytes) {
     if (!dst_host || !src_dev) return RGBDSLAM_E_ARG;
     hipError_t e = hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost);

@@ -108,3 +108,31 @@ def test_loop_track_loss_reseeds_model(pkg, orc, synth):
         same(rg.buffer(name), ref.buffer(name), name)
     rg.close()
     ref.close()
+
+
+def test_hip_path_reproduces_golden_fixture(pkg):
+    """The HIP path against the committed golden vectors (no oracle library involved)."""
+    import hashlib
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "slam_96x128.npz"))
+    n, m = g["depth"].shape[1:]
+    n_prim = g["Maskb0"].shape[0]
+    rg = pkg.RG(n, m, g["calib"], N_prim=n_prim, M_prim=n_prim)
+    for f in range(g["depth"].shape[0]):
+        rg.load_frame(np.ascontiguousarray(g["depth"][f]), np.ascontiguousarray(g["bgr"][f]))
+        assert rg.step() == int(g["status"][f])
+        R, t = rg.pose()
+        same(np.array(R + t, np.float32), g["poses"][f], "frame %d pose" % f)
+        if f == 1:
+            rg.set_planes(g["equations"], g["centers"])
+    same(rg.buffer("Label"), g["Label"], "Label")
+    same(rg.buffer("Mask"), g["Mask"], "Mask")
+    same(rg.buffer("RGBD")[..., 3], g["RGBD_w"], "RGBD.w")
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    for name in ("VMap", "NMap", "RGBD"):
+        same(sha(rg.buffer(name)), g["sha_" + name], name)
+    for k in range(g["equations"].shape[0]):
+        same(rg.buffer("Maskb%d" % k), g["Maskb%d" % k], "Maskb%d" % k)
+        same(sha(rg.buffer("Bump%d" % k)), g["sha_Bump%d" % k], "Bump%d" % k)
+        same(sha(rg.buffer("RGBb%d" % k)), g["sha_RGBb%d" % k], "RGBb%d" % k)
+    rg.close()

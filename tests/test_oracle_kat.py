@@ -1,0 +1,351 @@
+"""CPU tests of the oracle: analytic known answers and the committed golden vectors.
+
+The reference holds no tests or fixtures for this path ("parity unpinned"), so the oracle is pinned
+by (i) closed-form answers that follow from the reference's formulas and (ii) the golden file
+tests/golden/slam_96x128.npz written by tests/golden/make_golden.py."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIN20 = float(np.sin(np.deg2rad(20.0)))
+
+
+def flat_depth(n, m, z_m, factor=5000.0):
+    return np.full((n, m), int(round(z_m * factor)), np.uint16)
+
+
+# ---- stage 1 -------------------------------------------------------------------------------------
+def test_vertex_map_formula(orc, synth):
+    """D1/Kernel.cu:42-44: x = s*d*((j-cx)/fx), y = s*d*((i-cy)/fy), z = -s*d; rows flipped; d==0 -> 0."""
+    n, m = 12, 20
+    calib = synth.calib_for(n, m)
+    rng = np.random.default_rng(1)
+    d = rng.integers(0, 20000, (n, m)).astype(np.uint16)
+    d[3, 4] = 0
+    v = orc.vertex_map_kinect(d, calib)
+    s = np.float32(calib[9]) / np.float32(calib[10])
+    for (i, j) in [(0, 0), (5, 7), (n - 1, m - 1), (n - 1 - 3, 4)]:
+        dd = np.float32(d[n - 1 - i, j])
+        if dd == 0:
+            assert tuple(v[i, j]) == (0.0, 0.0, 0.0)
+            continue
+        x = (s * dd) * ((np.float32(j) - calib[2]) / calib[0])
+        y = (s * dd) * ((np.float32(i) - calib[3]) / calib[1])
+        assert v[i, j, 0] == np.float32(x) and v[i, j, 1] == np.float32(y) and v[i, j, 2] == np.float32(-s) * dd
+
+
+def test_cpy_char3(orc):
+    """D1/Kernel.cu:749-751: BGR8 -> RGB float /255.0 with the row flip."""
+    n, m = 4, 5
+    bgr = np.arange(n * m * 3, dtype=np.uint8).reshape(n, m, 3)
+    rgb = orc.cpy_char3(bgr)
+    exp = (bgr[::-1, :, ::-1].astype(np.float64) / 255.0).astype(np.float32)
+    assert np.array_equal(rgb, exp)
+
+
+def test_normals_fronto_parallel_plane(orc, synth):
+    """A fronto-parallel plane gives normals exactly (0,0,+1) after inverse=true (Kernel.cu:175-177,
+    288-291); the one-pixel border and holes are zero (Kernel.cu:134-137)."""
+    n, m = 24, 32
+    calib = synth.calib_for(n, m)
+    d = flat_depth(n, m, 1.5)
+    d[10, 10] = 0
+    v = orc.vertex_map_kinect(d, calib)
+    nm = orc.compute_normal(v, True)
+    inner = nm[1:-1, 1:-1]
+    hole_i = n - 1 - 10
+    ok = np.ones((n - 2, m - 2), bool)
+    ok[hole_i - 1, 10 - 1] = False
+    assert np.array_equal(inner[ok], np.tile(np.float32([0, 0, 1]), (ok.sum(), 1)))
+    assert not nm[0].any() and not nm[-1].any() and not nm[:, 0].any() and not nm[:, -1].any()
+    assert not nm[hole_i, 10].any()
+    assert np.array_equal(orc.compute_normal(v, False)[1:-1, 1:-1][ok], np.tile(np.float32([0, 0, -1]), (ok.sum(), 1)))
+
+
+def test_sobel_ramp_and_border(orc):
+    """3x3 Sobel, scale 1, reflect-101 (OpenCV BORDER_DEFAULT): a ramp a*j + b*i gives gx = 8a,
+    gy = 8b in the interior and 0 across a reflected border."""
+    n, m = 9, 11
+    ii, jj = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(m, dtype=np.float32), indexing="ij")
+    img = 0.5 * jj + 0.25 * ii
+    rgb = np.stack([img, img, img], -1).astype(np.float32)
+    out, gx, gy = orc.intensity_sobel(rgb)
+    assert np.allclose(out, img, atol=1e-6)
+    assert np.allclose(gx[1:-1, 1:-1], 4.0, atol=1e-5) and np.allclose(gy[1:-1, 1:-1], 2.0, atol=1e-5)
+    assert np.allclose(gx[:, 0], 0.0, atol=1e-5) and np.allclose(gx[:, -1], 0.0, atol=1e-5)
+    assert np.allclose(gy[0, :], 0.0, atol=1e-5) and np.allclose(gy[-1, :], 0.0, atol=1e-5)
+
+
+# ---- stage 2/3 ---------------------------------------------------------------------------------
+def test_icp_grid_divup(orc):
+    """divUp(n/fact, 8) (D1/ICP.cu:260-261, cudaTypes.cuh:53)."""
+    assert orc.icp_grid(480, 640, 1) == (60, 80)
+    assert orc.icp_grid(480, 640, 2) == (30, 40)
+    assert orc.icp_grid(480, 640, 4) == (15, 20)
+    assert orc.icp_grid(1080, 1920, 4) == (34, 60)
+    assert orc.icp_grid(37, 53, 2) == (3, 4)
+
+
+def test_identical_pair_gives_zero_rhs_and_identity(orc, pair):
+    """Model == current frame: every residual is exactly 0, so b = 0, the increment is the identity
+    and the pose does not move (SURVEY.md 8c KAT)."""
+    c = pair["calib"]
+    I, z = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)
+    img, gx, gy = orc.intensity_sobel(pair["rgb0"])
+    A, b, sums = orc.estimate_system(c[:4], I, z, pair["v0"], pair["n0"], pair["rgb0"], gx, gy, pair["v0"], pair["n0"],
+                                     pair["rgbd0"], 0.05, SIN20, 2)
+    assert not b.any()
+    assert np.array_equal(A, A.T) and np.all(np.diag(A) > 0)
+    ok, R, t, trace = orc.align_gauss_newton(orc.icp_params(), c[:4], pair["v0"], pair["n0"], pair["rgb0"], pair["v0"],
+                                             pair["n0"], pair["rgbd0"], I, z, I, z)
+    assert ok and np.array_equal(R, I) and not t.any()
+    assert len(trace) == 3          # converged at iteration 0 of each level (RG.cpp:889)
+
+
+def test_known_offset_is_recovered(orc, pair):
+    """Config 1: rot (0.5,-0.3,0.2) deg, t (5,-3,4) mm recovered to depth-quantisation accuracy."""
+    c = pair["calib"]
+    I, z = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)
+    ok, R, t, trace = orc.align_gauss_newton(orc.icp_params(), c[:4], pair["v1"], pair["n1"], pair["rgb1"], pair["v0"],
+                                             pair["n0"], pair["rgbd0"], I, z, I, z)
+    assert ok and 3 <= len(trace) <= 12
+    assert np.abs(R.reshape(3, 3).T - pair["R1"]).max() < 2e-4      # R is column-major
+    assert np.abs(t - pair["t1"]).max() < 3e-4
+    # rows of the trace: 27 sums + 6-vector solution; the first solution is the biggest step
+    assert np.abs(trace[0, 27:]).max() > np.abs(trace[-1, 27:]).max()
+
+
+def test_system_matches_blockwise_float64_sum(orc, pair):
+    """The two-stage reduction (8x8 tree + 512-strided chains, ICP.cu:28-70) agrees with a float64
+    sum of the same per-block partials to float32 accuracy."""
+    c = pair["calib"]
+    I, z = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)
+    buf, corr = orc.icp_match(c[:4], I, z, pair["v1"], pair["n1"], pair["rgb1"], pair["gx1"], pair["gy1"], pair["v0"],
+                              pair["n0"], pair["rgbd0"], 0.05, SIN20, 1)
+    sums = orc.icp_reduce(buf)
+    ref = buf.astype(np.float64).sum(axis=1)
+    assert np.allclose(sums, ref, rtol=2e-5, atol=1e-7)
+    assert corr.min() >= -1 and corr.max() < 480 * 640 and (corr >= 0).sum() > 100000
+
+
+def test_dense_helpers(orc):
+    rng = np.random.default_rng(3)
+    Mx = rng.normal(size=(6, 6))
+    A = (Mx @ Mx.T + 6 * np.eye(6)).astype(np.float32)
+    b = rng.normal(size=6).astype(np.float32)
+    rc, x = orc.llt_solve6(A, b)
+    assert rc == 0 and np.allclose(x, np.linalg.solve(A.astype(np.float64), b), rtol=1e-4, atol=1e-5)
+    assert np.isclose(orc.det6(A), np.linalg.det(A.astype(np.float64)), rtol=1e-4)
+    assert orc.llt_solve6(-A, b)[0] == 1                            # not positive definite
+    R = np.asarray(importlib.import_module("rgb-d-slam_amd.synth").euler_xyz(0.1, -0.2, 0.3), np.float32)
+    inv = orc.inverse3(R.T.reshape(-1)).reshape(3, 3).T
+    assert np.allclose(inv, R.T, atol=1e-6)
+
+
+# ---- stage 4 -----------------------------------------------------------------------------------
+def test_merge_depth_rules(orc, synth):
+    """The five branches of MergeDepthOffKernel (D1/Kernel.cu:468-523) on hand-made pixels."""
+    n, m = 1, 6
+    calib = synth.calib_for(n, m)
+    f = 5000.0
+    #            no input  empty model  occluder   violation  average   saturate
+    dv = np.array([0.0,      1.0,         1.0,       2.0,       1.004,    1.0])
+    dp = np.array([1.0,      0.0,         1.5,       1.0,       1.0,      1.0])
+    mk = np.array([15,       10,          20,        20,        13,       255], np.uint8)
+    depth = np.rint(dv * f).astype(np.uint16).reshape(1, m)
+    rgbd = np.zeros((n, m, 4), np.float32)
+    rgbd[0, :, 3] = (dp / 100.0).astype(np.float32)
+    rgb = np.full((n, m, 3), 0.25, np.float32)
+    out, mask = orc.merge_depth_off(rgbd, depth, rgb, mk.reshape(1, m), calib)
+    assert np.all(out[..., :3] == 0.25)                            # colour always replaced (Kernel.cu:463-465)
+    w = out[0, :, 3] * 100.0
+    assert np.isclose(w[0], 1.0) and mask[0, 0] == 15              # dv < 0.1: untouched
+    assert np.isclose(w[1], 1.0) and mask[0, 1] == 11              # empty model: take the input
+    assert np.isclose(w[2], 1.0) and mask[0, 2] == 11              # dv < dp - 0.2: occluder replaces
+    assert np.isclose(w[3], 1.0) and mask[0, 3] == 10              # dv > dp + max(1,dv)*0.2: visibility violation
+    assert np.isclose(w[4], (1.004 + 3 * 1.0) / 4.0, atol=1e-6) and mask[0, 4] == 14   # running average, count+1
+    assert mask[0, 5] == 255                                        # saturates at 255
+
+
+def plane_param(n_prim):
+    # plane z = -2 (normal +z towards the camera), e1 = x, e2 = y, image centred on the view axis
+    scale = np.float32(2.0 / 0.004)
+    half = np.float32(n_prim * 0.004 / 2.0)
+    return np.array([0, 0, 1, -2.0, scale, scale, -half, -half, 1, 0, 0, 0, 1, 0], np.float32)
+
+
+def test_bump_codec_round_trip(orc, synth):
+    """F4 -> R7: fusing a frame into a Bump image and decoding it returns the fused points to within
+    half a quantisation step: 4 mm/60000/2 in plane, 0.25 mm along the normal."""
+    n, m, n_prim = 48, 64, 256
+    calib = synth.calib_for(n, m)
+    rng = np.random.default_rng(5)
+    depth = np.rint((2.0 + 0.01 * rng.standard_normal((n, m))) * 5000).astype(np.uint16)
+    v = orc.vertex_map_kinect(depth, calib)
+    rgbd = np.zeros((n, m, 4), np.float32)
+    rgbd[..., :3] = rng.random((n, m, 3), dtype=np.float32)
+    mask = np.full((n, m), 11, np.uint8)
+    label = np.ones((n, m), np.uint8)
+    bump = [np.zeros((n_prim, n_prim, 3), np.uint16)]
+    rgbb = [np.zeros((n_prim, n_prim, 3), np.uint8)]
+    maskb = [np.zeros((n_prim, n_prim), np.uint8)]
+    claim = [np.zeros((n_prim, n_prim), np.uint64)]
+    param = [plane_param(n_prim)]
+    pose = np.eye(4, dtype=np.float32).T.reshape(-1)
+    orc.update(bump, rgbb, maskb, param, claim, 1, v, rgbd, mask, label, pose)
+    vd, cd, md = orc.vertex_from_bump(bump[0], rgbb[0], maskb[0], param[0])
+    filled = maskb[0] == 11
+    assert filled.sum() > 500
+    # every fused point must be reproduced by the cell it fell in
+    a = ((v[..., 0] - param[0][6]) * param[0][4] / 2.0)
+    b = ((v[..., 1] - param[0][7]) * param[0][5] / 2.0)
+    ci, cj = np.floor(a).astype(int), np.floor(b).astype(int)
+    inside = (ci >= 0) & (ci < n_prim) & (cj >= 0) & (cj < n_prim)
+    winners = 0
+    for i, j in zip(*np.nonzero(inside)):
+        p = vd[ci[i, j], cj[i, j]]
+        err = np.abs(p - v[i, j])
+        if err[0] <= 0.004 / 60000 / 2 + 1e-6 and err[1] <= 0.004 / 60000 / 2 + 1e-6 and err[2] <= 0.00025 + 1e-6:
+            winners += 1
+            assert np.abs(cd[ci[i, j], cj[i, j], :3] - rgbd[i, j, :3]).max() <= 0.5 / 255 + 1e-6
+    assert winners == filled.sum()          # exactly one frame pixel wins each filled cell
+    assert not vd[~filled].any() and not md[~filled].any()
+    # a second, identical update changes nothing (gate mask_curr > cell mask, Primitive.cu:341)
+    before = (bump[0].copy(), maskb[0].copy())
+    orc.update(bump, rgbb, maskb, param, claim, 2, v, rgbd, mask, label, pose)
+    assert np.array_equal(before[0], bump[0]) and np.array_equal(before[1], maskb[0])
+    # out-of-view pixels (mask 0) erode the cell: 11 -> cleared to 10 (Primitive.cu:313-326)
+    orc.update(bump, rgbb, maskb, param, claim, 3, v, rgbd, np.zeros_like(mask), label, pose)
+    assert set(np.unique(maskb[0])) <= {0, 10} and not bump[0][maskb[0] == 10].any()
+
+
+def test_update_plane_partition_is_a_partition(orc, synth):
+    """Plane-partitioned fusion: shards [0,1) + [1,3) write exactly what [0,3) writes."""
+    n, m, n_prim = 60, 80, 128
+    calib = synth.calib_for(n, m)
+    d, c = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    v = orc.vertex_map_kinect(d, calib)
+    nm = orc.compute_normal(v)
+    rgbd = orc.add_zbuff_off(d, orc.cpy_char3(c), calib)
+    eq, centers = synth.plane_equations()
+    pose = np.eye(4, dtype=np.float32).T.reshape(-1)
+    label = orc.seed_labels(v, nm, pose, eq)
+    mask = orc.init_mask(rgbd)
+
+    def planes():
+        P = []
+        for k in range(3):
+            p = np.zeros(14, np.float32)
+            p[0:3], p[3], p[4:6] = eq[k, 0:3], eq[k, 9], 500.0
+            p[6] = centers[k] @ eq[k, 3:6] - n_prim * 0.004 / 2
+            p[7] = centers[k] @ eq[k, 6:9] - n_prim * 0.004 / 2
+            p[8:11], p[11:14] = eq[k, 3:6], eq[k, 6:9]
+            P.append(p)
+        return ([np.zeros((n_prim, n_prim, 3), np.uint16) for _ in range(3)], [np.zeros((n_prim, n_prim, 3), np.uint8) for _ in range(3)],
+                [np.zeros((n_prim, n_prim), np.uint8) for _ in range(3)], P, [np.zeros((n_prim, n_prim), np.uint64) for _ in range(3)])
+
+    full = planes()
+    orc.update(*full, 1, v, rgbd, mask, label, pose)
+    part = planes()
+    orc.update(*part, 1, v, rgbd, mask, label, pose, 0, 1)
+    orc.update(*part, 1, v, rgbd, mask, label, pose, 1, 3)
+    assert sum(int((mk > 10).sum()) for mk in full[2]) > 200
+    for k in range(3):
+        assert np.array_equal(full[0][k], part[0][k]) and np.array_equal(full[1][k], part[1][k]) and np.array_equal(full[2][k], part[2][k])
+
+
+# ---- stage 5 -----------------------------------------------------------------------------------
+def test_prediction_identity_warp_reproduces_model(orc, pair):
+    """Rasterising the un-moved model mesh returns the model depth at every pixel whose quads
+    survive trimming: the rendered value is the ray/mesh intersection depth."""
+    c, v, rgbd = pair["calib"], pair["v0"], pair["rgbd0"]
+    tex, zbuf = orc.raster(v, rgbd, c)
+    v2, rgbd2 = orc.read_frame(tex, c)
+    drawn = tex[..., 3] > 0
+    assert np.array_equal(drawn, zbuf != np.uint64(0xFFFFFFFFFFFFFFFF))   # z-buffer keys: (depth bits, ~triangle id)
+    assert drawn.mean() > 0.9
+    assert np.abs(tex[..., 3][drawn] - rgbd[..., 3][drawn]).max() < 2e-6     # depth/100, f32 rounding only
+    assert np.abs(tex[..., :3][drawn] - rgbd[..., :3][drawn]).max() < 1e-5
+    assert np.abs(v2[drawn] - v[drawn]).max() < 2e-4
+    assert not v2[~drawn].any() and not rgbd2[~drawn].any()
+    # index-buffer path (QuadTrimFrame output) == inline trimming
+    idx = orc.quad_trim_frame(v, 0.1)
+    tex_i, _ = orc.raster(v, rgbd, c, index=idx)
+    assert np.array_equal(tex, tex_i)
+    kept = idx.any(axis=1)
+    assert kept.mean() > 0.9                                           # quads across the plane creases are kept
+    vh = v.copy()
+    vh[100:120, 100:120] *= 2.0                                        # a block twice as far: its rim quads are trimmed
+    cut = ~orc.quad_trim_frame(vh, 0.1).any(axis=1)
+    assert 70 < cut.sum() < 400 and cut.reshape(479, 639)[99, 99:120].all() and not cut.reshape(479, 639)[105:115, 105:115].any()
+
+
+def test_near_far_clipping(orc, synth):
+    """Znear 0.5 / Zfar 10 (GP-demo.cpp:18-19) remove geometry from the prediction."""
+    n, m = 16, 16
+    calib = synth.calib_for(n, m)
+    for z, seen in ((0.3, False), (1.0, True), (12.0, False)):
+        d = flat_depth(n, m, z)
+        v = orc.vertex_map_kinect(d, calib)
+        rgbd = orc.add_zbuff_off(d, np.ones((n, m, 3), np.float32), calib)
+        tex, _ = orc.raster(v, rgbd, calib, thresh=10.0)             # no trimming: clipping alone decides
+        assert bool(tex[..., 3].any()) == seen
+
+
+def test_transform_and_project_mask_round_trip(orc, synth, pair):
+    """ProjectMask with the inverse of the warp brings a mask back onto itself (Kernel.cu:634-667)."""
+    c, v, rgbd = pair["calib"], pair["v0"], pair["rgbd0"]
+    mask = (np.arange(480 * 640).reshape(480, 640) % 251 + 1).astype(np.uint8)
+    ident = np.eye(4, dtype=np.float32).T.reshape(-1)
+    out = orc.project_mask(ident, c, mask, v)
+    valid = v[..., 2] != 0
+    assert np.array_equal(out[valid], mask[valid]) and not out[~valid].any()
+    # a pure depth shift keeps pixels on their rays... a lateral shift moves them off the image edge -> 0
+    P = np.eye(4, dtype=np.float32)
+    P[0, 3] = 5.0
+    out = orc.project_mask(P.T.reshape(-1), c, mask, v)
+    assert not out[valid][-1000:].all()
+    v2, r2 = orc.transform_vertex_map(P.T.reshape(-1), v, rgbd)
+    assert np.allclose(v2[valid][:, 0], v[valid][:, 0] + 5.0) and np.array_equal(v2[~valid], v[~valid])
+    assert np.allclose(r2[..., 3][valid], -v2[..., 2][valid] / 100.0)
+
+
+def test_segment_grows_labels(orc, synth):
+    """3 passes of SegmentKernel grow a seeded label by exactly 3 pixels on a plane (RG.cu:252-320)."""
+    n, m = 40, 40
+    calib = synth.calib_for(n, m)
+    d = flat_depth(n, m, 2.0)
+    v = orc.vertex_map_kinect(d, calib)
+    nm = orc.compute_normal(v)
+    eq = np.array([[0, 0, 1, 1, 0, 0, 0, 1, 0, -2.0]], np.float32)
+    pose = np.eye(4, dtype=np.float32).T.reshape(-1)
+    lab = np.zeros((n, m), np.uint8)
+    lab[20, 20] = 1
+    out = orc.segment(lab, v, nm, pose, eq)
+    exp = np.zeros((n, m), np.uint8)
+    exp[17:24, 17:24] = 1
+    assert np.array_equal(out, exp)
+    # a plane the pixels do not lie on is never adopted
+    eq_far = eq.copy()
+    eq_far[0, 9] = -3.0
+    assert orc.segment(lab, v, nm, pose, eq_far).sum() == 1
+
+
+# ---- golden vectors ---------------------------------------------------------------------------
+def test_oracle_reproduces_golden():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from oracle import oracle as orc
+    g = np.load(os.path.join(HERE, "golden", "slam_96x128.npz"))
+    out = mg.run_oracle(orc, g["calib"], g["depth"], g["bgr"], g["equations"], g["centers"])
+    for k, val in out.items():
+        a, b = np.asarray(val), g[k]
+        if a.dtype.kind == "f":
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+        else:
+            assert np.array_equal(a, b), k
+    assert list(g["status"]) == [2, 1, 1, 1, 1] and int(g["align_ok"][0]) == 1
