@@ -37,7 +37,7 @@ POOL_FRAMES = 60           # distinct synthetic frames, visited ping-pong so ste
 # Algorithmic bytes per unit (SURVEY.md 8d / DESIGN.md "kernels"), per launch of each kernel.
 def algo_bytes(kernel, n, m, level_iters):
     P = n * m
-    if kernel == "k_icp_match":
+    if kernel == "k_icp_iter":
         # 80 B per sampled model pixel per executed iteration, all three levels summed
         return sum(80 * (n // f) * (m // f) * it for f, it in zip((1, 2, 4), level_iters))
     per_px = {"k_update<false>": 30, "k_update<true>": 41, "k_merge_depth_off": 48, "k_compute_normal": 24,
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
-    ap.add_argument("--kernel", default="k_icp_match", help="kernel whose roofline is reported")
+    ap.add_argument("--kernel", default="k_icp_iter", help="kernel whose roofline is reported")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-in-timed-region", action="store_true",
                     help="record the roofline events inside the timed region instead of in a second pass")

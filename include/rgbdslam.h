@@ -49,6 +49,10 @@ const char *rgbdslam_version(void);
  * profile_read synchronises, returns the summed durations and the launch count, and resets. */
 int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_name);
 int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *launches);
+/* Debug: int64[7] device words that receive wall_clock64 stamps (10 ns ticks) of the phases of the
+ * last ICP iteration kernel: [0] first workgroup start, [1..6] the tail workgroup's start, rounds
+ * done, chain sums published, arrival counted, tree done, solve done.  NULL switches it off. */
+int rgbdslam_debug_icp_timing(rgbdslam_ctx *ctx, long long *timing7_dev);
 
 /* Kernel.cuh:7-8   void SetCalibrationMatrix(float *Calib_CPU); FreeCalibrationMatrix()
  * calib = {fx, fy, cx, cy, k1..k5 (unused), ds, factor} (GP-demo.cpp:17,404). */
@@ -73,7 +77,8 @@ int rgbdslam_intensity_sobel(rgbdslam_ctx *ctx, const float *rgb, float *img, si
                              float *gx, size_t gx_pitch, float *gy, size_t gy_pitch, int n, int m);
 
 /* ---- stage 2+3: ICP normal equations ------------------------------------------------------ */
-/* ICP.cuh:6-7  void AllocBuffers(int n, int m); void FreeBuffers()  (n, m = 8x8-block grid) */
+/* ICP.cuh:6-7  void AllocBuffers(int n, int m); void FreeBuffers()  (n, m = 8x8-block grid; the
+ * scratch here is a fixed 27 x 512 floats, so the arguments only have to be positive) */
 int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid_cols);
 int rgbdslam_free_buffers(rgbdslam_ctx *ctx);
 /* ICP.cuh:9-12  void EstimateSystemGaussNewton(float *Rcurr_dev, float *tcurr_dev, float *VMap,
@@ -81,9 +86,9 @@ int rgbdslam_free_buffers(rgbdslam_ctx *ctx);
  *   float *NMap_prev, float *RGB_prev, float *intr, float distThres, float angleThres,
  *   int n_row, int m_col, float *A, float *b, int fact)
  * Rcurr_dev(9) tcurr_dev(3) intr(4) are DEVICE pointers; A(36, row-major) b(6) HOST outputs.
- * BLOCKING (like the reference's cudaMemcpy D2H).  The 27 sums are accumulated in exactly the
- * reference's order (8x8-block tree, then 512-strided chains + tree) and are therefore
- * bit-identical to the oracle's.  corr_dev (optional, may be NULL): int32[n*m] debug map,
+ * BLOCKING (like the reference's cudaMemcpy D2H).  One launch does what the reference's two
+ * kernels do; the 27 sums are accumulated in exactly the reference's order (8x8-block tree, then
+ * 512-strided chains + tree) and are therefore bit-identical to the oracle's.  corr_dev (optional, may be NULL): int32[n*m] debug map,
  * -1 or the matched current-frame pixel index, indexed by model pixel. */
 int rgbdslam_estimate_system_gauss_newton(rgbdslam_ctx *ctx, const float *Rcurr_dev,
                                           const float *tcurr_dev, const float *VMap,
@@ -113,6 +118,24 @@ int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp_params *pr
                                 const float *VMap_prev, const float *NMap_prev,
                                 const float *RGB_prev, int n_row, int m_col,
                                 float *pose_state_dev, int32_t *status_dev, float *trace_dev);
+
+/* Row-sharded form of the same loop (no reference counterpart: the reference is single-GPU;
+ * SURVEY.md 8e / BASELINE.json configs[3]).  Each rank owns the 8x8-block rows
+ * [block_row_lo, block_row_hi) of the level's block grid (divUp(n/2^lvl, 8) rows) and produces its
+ * own 27 partial sums; the caller all-gathers them (RCCL, stream-ordered) and every rank runs the
+ * identical solve on the rank-ordered total, so all ranks hold bit-identical poses.  Sequence:
+ * align_begin; for lvl = prm->lvl-1..0, iter = 0..max_iter[lvl]+1: align_band_system, <all-gather>,
+ * align_solve_gathered; align_end.  All asynchronous; converged/failed iterations exit on device. */
+int rgbdslam_align_begin(rgbdslam_ctx *ctx, const float *pose_state_dev, int32_t *status_dev);
+int rgbdslam_align_band_system(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap,
+                               const float *NMap, const float *RGB, const float *Gx, size_t gx_pitch,
+                               const float *Gy, size_t gy_pitch, const float *VMap_prev,
+                               const float *NMap_prev, const float *RGB_prev, int n_row, int m_col,
+                               int lvl, int iter, int block_row_lo, int block_row_hi, float *sums27_dev);
+int rgbdslam_align_solve_gathered(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm,
+                                  const float *gathered_dev, int parts, const float *pose_state_dev,
+                                  int lvl, int iter, float *trace_dev);
+int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int32_t *status_dev);
 
 /* ---- stage 4: fusion ---------------------------------------------------------------------- */
 /* Kernel.cuh:21  void MergeDepthOff(float *RGB_predicted, DevMem2D_<unsigned short> depth,

@@ -34,8 +34,9 @@ struct rgbdslam_ctx {
     PoseV pose;
     bool have_calib;
     // ICP.cu:5-7 globals
-    float *buf_dev;      // f32[27][nblk]
-    size_t buf_blocks;   // capacity in 8x8 blocks
+    float *buf_dev;      // f32[27][512] chain sums (first reduction stage, ICP.cu:57-58)
+    long long *icp_timing_dev;  // debug (rgbdslam_debug_icp_timing)
+    unsigned int *ticket_dev;   // last-workgroup-done counter of k_icp_iter
     float *outbuf_dev;   // f32[27]
     float *out_host;     // pinned f32[27]
     IcpState *icp_state; // device

@@ -19,7 +19,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->stream = (hipStream_t)stream;
     c->have_calib = false;
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
-    c->buf_dev = nullptr; c->buf_blocks = 0; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr;
+    c->buf_dev = nullptr; c->ticket_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr;
     c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0;
     *out = c;
     return 0;
@@ -105,5 +105,12 @@ extern "C" int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *l
     *total_ms = tot;
     *launches = ctx->prof_n;
     ctx->prof_n = 0;
+    return 0;
+}
+
+// debug: 7 x int64 device words receiving phase time stamps of the LAST k_icp_iter launch
+extern "C" int rgbdslam_debug_icp_timing(rgbdslam_ctx *ctx, long long *timing7_dev) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    ctx->icp_timing_dev = timing7_dev;
     return 0;
 }

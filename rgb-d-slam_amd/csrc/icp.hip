@@ -9,41 +9,69 @@
 // (D1/ICP.cu:50-70): the 27 sums are bit-identical to a serial restatement of the reference.
 #include "common.hpp"
 
-#define ICP_WAVES 4   // waves (= 8x8 blocks) per workgroup
+#define ICP_MAX_WAVES 8   // waves (= 8x8 blocks in flight) per workgroup
+#define ICP_TICKET_GROUP 16
+#define ICP_TICKET_WORDS (32 * (1 + 512 / ICP_TICKET_GROUP))
+#define ICP_CHAINS 512     // STRIDE (D1/cudaTypes.cuh:46): chains of ReduceKernel
 
 struct IcpRow { float g[7]; float c[7]; };
 
-// D1/ICP.cu:72-146 searchGauss + 164-205 row construction.  Returns false -> zero rows.
-__device__ __forceinline__ bool icp_rows(size_t indx, const float *__restrict__ intr, const float *__restrict__ R,
-                                         const float *__restrict__ t, const float *__restrict__ VMap,
-                                         const float *__restrict__ NMap, const float *__restrict__ RGB,
-                                         const float *__restrict__ Gx, size_t gxp, const float *__restrict__ Gy, size_t gyp,
-                                         const float *__restrict__ VMap_prev, const float *__restrict__ NMap_prev,
-                                         const float *__restrict__ RGBD_prev, float distThres, float angleThres,
-                                         int n, int m, IcpRow &o, int &proj) {
-    F3 np = ld3(NMap_prev, indx);
-    if (is_zero3(np)) return false;
-    F3 vp = ld3(VMap_prev, indx);
-    float4 cp = *(const float4 *)(RGBD_prev + 4 * indx);
+// D1/ICP.cu:72-146 searchGauss + 164-205 row construction, split so that every memory access of a
+// stage is issued before anything waits on it (the kernel is a chain of dependent memory round
+// trips; the arithmetic and its order are untouched).
+struct IcpModelPx { F3 np, vp; float4 cp; };
+struct IcpCurrPx { F3 nc, s, cc; float gx, gy; };
+struct IcpProj { float d0, d1, d2, n0, n1, n2, az; int pu, pv; size_t pidx; };
 
-    float d0 = ((R[0] * vp.x + R[3] * vp.y) + R[6] * vp.z) + t[0];
-    float d1 = ((R[1] * vp.x + R[4] * vp.y) + R[7] * vp.z) + t[1];
-    float d2 = ((R[2] * vp.x + R[5] * vp.y) + R[8] * vp.z) + t[2];
-    float n0 = (R[0] * np.x + R[3] * np.y) + R[6] * np.z;
-    float n1 = (R[1] * np.x + R[4] * np.y) + R[7] * np.z;
-    float n2 = (R[2] * np.x + R[5] * np.y) + R[8] * np.z;
+__device__ __forceinline__ IcpModelPx icp_load_model(size_t indx, const float *__restrict__ VMap_prev,
+                                                     const float *__restrict__ NMap_prev, const float *__restrict__ RGBD_prev) {
+    IcpModelPx mp;
+    mp.np = ld3(NMap_prev, indx);
+    mp.vp = ld3(VMap_prev, indx);
+    mp.cp = *(const float4 *)(RGBD_prev + 4 * indx);
+    return mp;
+}
+__device__ __forceinline__ IcpProj icp_project(const IcpModelPx &mp, const float *R, const float *t, const float *intr, int n, int m) {
+    IcpProj p;
+    const F3 &vp = mp.vp, &np = mp.np;
+    p.d0 = ((R[0] * vp.x + R[3] * vp.y) + R[6] * vp.z) + t[0];
+    p.d1 = ((R[1] * vp.x + R[4] * vp.y) + R[7] * vp.z) + t[1];
+    p.d2 = ((R[2] * vp.x + R[5] * vp.y) + R[8] * vp.z) + t[2];
+    p.n0 = (R[0] * np.x + R[3] * np.y) + R[6] * np.z;
+    p.n1 = (R[1] * np.x + R[4] * np.y) + R[7] * np.z;
+    p.n2 = (R[2] * np.x + R[5] * np.y) + R[8] * np.z;
+    p.az = __builtin_fabsf(p.d2);
+    int pu = f2i_rn((p.d0 / p.az) * intr[0] + intr[2]);
+    int pv = f2i_rn((p.d1 / p.az) * intr[1] + intr[3]);
+    p.pu = min(m - 1, max(0, pu));
+    p.pv = min(n - 1, max(0, pv));
+    p.pidx = (size_t)p.pv * m + p.pu;
+    return p;
+}
+__device__ __forceinline__ IcpCurrPx icp_gather(const IcpProj &p, const float *__restrict__ VMap, const float *__restrict__ NMap,
+                                                const float *__restrict__ RGB, const float *__restrict__ Gx, size_t gxp,
+                                                const float *__restrict__ Gy, size_t gyp) {
+    IcpCurrPx c;
+    c.nc = ld3(NMap, p.pidx);
+    c.s = ld3(VMap, p.pidx);
+    c.cc = ld3(RGB, p.pidx);
+    c.gx = *(const float *)((const char *)Gx + (size_t)p.pv * gxp + 4 * (size_t)p.pu);
+    c.gy = *(const float *)((const char *)Gy + (size_t)p.pv * gyp + 4 * (size_t)p.pu);
+    return c;
+}
+
+// Returns false -> zero rows.
+__device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr, const IcpCurrPx &cu, const float *intr,
+                                         float distThres, float angleThres, IcpRow &o, int &proj) {
+    if (is_zero3(mp.np)) return false;
+    const float4 cp = mp.cp;
+    const float d0 = pr.d0, d1 = pr.d1, d2 = pr.d2, n0 = pr.n0, n1 = pr.n1, n2 = pr.n2, az = pr.az;
+    const size_t pidx = pr.pidx;
     float i_prev = (float)((double)((cp.x + cp.y) + cp.z) / 3.0);
 
-    float az = __builtin_fabsf(d2);
-    int pu = f2i_rn((d0 / az) * intr[0] + intr[2]);
-    int pv = f2i_rn((d1 / az) * intr[1] + intr[3]);
-    pu = min(m - 1, max(0, pu));
-    pv = min(n - 1, max(0, pv));
-    size_t pidx = (size_t)pv * m + pu;
-
-    F3 nc = ld3(NMap, pidx);
+    F3 nc = cu.nc;
     if (is_zero3(nc)) return false;
-    F3 s = ld3(VMap, pidx);
+    F3 s = cu.s;
     float ex = d0 - s.x, ey = d1 - s.y, ez = d2 - s.z;
     float dist = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
     if (dist > distThres) return false;
@@ -53,10 +81,10 @@ __device__ __forceinline__ bool icp_rows(size_t indx, const float *__restrict__ 
     float ang = __builtin_sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
     if (ang > angleThres) return false;
 
-    F3 cc = ld3(RGB, pidx);
+    F3 cc = cu.cc;
     float i_curr = (float)((double)((cc.x + cc.y) + cc.z) / 3.0);
-    float g0 = (float)((double)*(const float *)((const char *)Gx + (size_t)pv * gxp + 4 * (size_t)pu) / 8.0);
-    float g1 = (float)((double)*(const float *)((const char *)Gy + (size_t)pv * gyp + 4 * (size_t)pu) / 8.0);
+    float g0 = (float)((double)cu.gx / 8.0);
+    float g1 = (float)((double)cu.gy / 8.0);
     float g2 = i_curr - i_prev;
     proj = (int)pidx;
 
@@ -99,76 +127,221 @@ __device__ __forceinline__ bool icp_rows(size_t indx, const float *__restrict__ 
     return true;
 }
 
-// fold 64 lane values in the pairing of reduce<64>: reference tid = col*8 + row, lane = row*8 + col,
-// so tid offsets 32,16,8,4,2,1 are lane offsets 4,2,1,32,16,8.  Result valid in lane 0.
-__device__ __forceinline__ float fold64(float v) {
-    v = v + __shfl_down(v, 4);
-    v = v + __shfl_down(v, 2);
-    v = v + __shfl_down(v, 1);
-    v = v + __shfl_down(v, 32);
-    v = v + __shfl_down(v, 16);
-    v = v + __shfl_down(v, 8);
-    return v;
+// ---- 27-term block sum in the pairing of reduce<64> (D1/ICP.cu:28-48) -----------------------------
+// Reference tid = col*8 + row, lane = row*8 + col, so the tree's tid offsets 32,16,8,4,2,1 are the
+// lane bits 2,1,0,5,4,3.  A butterfly over those bits in that order leaves in every lane the same
+// bits as the tree leaves in v[0] (IEEE addition is commutative, the pairing is unchanged).
+// Instead of 27 independent butterflies (162 cross-lane moves) the terms are split between the two
+// partners at every level -- 14+7+4+2+1+1 = 29 moves -- and each lane ends with ONE finished term:
+//   term(lane) = 14*b2 + 7*b1 + 4*b0 + 2*b5 + b4,  valid unless (b0 & b5 & b4) or term == 27.
+template <int HALF, int XOR>
+__device__ __forceinline__ void fold_level(const float *in, int n_in, float *out, bool hi) {
+#pragma unroll
+    for (int k = 0; k < HALF; k++) {
+        float lo_v = in[k];
+        float hi_v = (HALF + k < n_in) ? in[HALF + k] : 0.0f;
+        float send = hi ? lo_v : hi_v;          // what the partner keeps
+        float keep = hi ? hi_v : lo_v;
+        out[k] = keep + __shfl_xor(send, XOR);
+    }
+}
+__device__ __forceinline__ float fold27(const float *v, int lane, int &term, bool &valid) {
+    float a[14], b[7], c[4], d[2], e[1];
+    bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1, b5 = lane & 32, b4 = lane & 16;
+    fold_level<14, 4>(v, 27, a, b2);
+    fold_level<7, 2>(a, 14, b, b1);
+    fold_level<4, 1>(b, 7, c, b0);
+    fold_level<2, 32>(c, 4, d, b5);
+    fold_level<1, 16>(d, 2, e, b4);
+    float r = e[0] + __shfl_xor(e[0], 8);
+    term = (b2 ? 14 : 0) + (b1 ? 7 : 0) + (b0 ? 4 : 0) + (b5 ? 2 : 0) + (b4 ? 1 : 0);
+    valid = term < 27 && !(b0 && b5 && b4);
+    return r;
 }
 
-// Grid: x over groups of ICP_WAVES block-columns, y over block-rows.  state (optional) gates the
-// launch for the device-resident loop: skip when the level already converged or tracking failed.
-__global__ __launch_bounds__(64 * ICP_WAVES)
-void k_icp_match(const float *__restrict__ intr, const float *__restrict__ Rcurr, const float *__restrict__ tcurr,
-                 const float *__restrict__ VMap, const float *__restrict__ NMap, const float *__restrict__ RGB,
-                 const float *__restrict__ Gx, size_t gxp, const float *__restrict__ Gy, size_t gyp,
-                 const float *__restrict__ VMap_prev, const float *__restrict__ NMap_prev,
-                 const float *__restrict__ RGBD_prev, float distThres, float angleThres, int n, int m, int fact,
-                 int grid_rows, int grid_cols, float *__restrict__ buf, int32_t *__restrict__ corr,
-                 const IcpState *__restrict__ state, int iter) {
-    if (state && (state->fail || (iter > 0 && state->cvg))) return;
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int bc = blockIdx.x * ICP_WAVES + wave, br = blockIdx.y;
-    if (bc >= grid_cols) return;   // whole wave exits together
-    int i = br * 8 + (lane >> 3), j = bc * 8 + (lane & 7);
-    IcpRow r;
-#pragma unroll
-    for (int k = 0; k < 7; k++) { r.g[k] = 0.0f; r.c[k] = 0.0f; }
-    if (i * fact < n && j * fact < m) {
-        size_t idx = (size_t)(i * fact) * m + (size_t)(j * fact);
-        int proj = -1;
-        IcpRow q;
-        bool ok = icp_rows(idx, intr, Rcurr, tcurr, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev, NMap_prev, RGBD_prev,
-                           distThres, angleThres, n, m, q, proj);
-        if (ok) r = q;
-        if (corr) corr[idx] = ok ? proj : -1;
-    }
-    int nblk = grid_rows * grid_cols;
-    int blk = br + bc * grid_rows;                       // D1/ICP.cu:238
-    int term = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-#pragma unroll
-        for (int l = k; l < 7; l++) {
-            float v = fold64(r.g[k] * r.g[l] + r.c[k] * r.c[l]);
-            if (lane == 0) buf[blk + (size_t)term * nblk] = v;
-            term++;
+// ---- one Gauss-Newton iteration: match + both reduction stages (+ solve) in ONE launch -----------
+// Workgroup t owns "chain" t of ReduceKernel (D1/ICP.cu:57-58): the 8x8 blocks t, t+512, t+1024...
+// Its waves compute those blocks' 27 partial sums (one wave = one block), wave 0 adds them in chain
+// order, and the last workgroup to finish (ticket counter) folds the 512 chain sums per term in the
+// pairing of reduce<512> and runs the 6x6 solve -- so one launch replaces the reference's
+// memset + MatchKernel + memset + ReduceKernel + D2H + host solve + H2D (D1/ICP.cu:254-286,
+// RG.cpp:851-901) with bit-identical sums.
+struct IcpIterArgs {
+    const float *intr, *R, *t;                       // device scalars (user buffers or &IcpState fields)
+    const float *VMap, *NMap, *RGB, *Gx, *Gy;
+    size_t gxp, gyp;
+    const float *VMap_prev, *NMap_prev, *RGBD_prev;
+    float distThres, angleThres;
+    int n, m, fact;
+    int grid_rows, grid_cols;                        // full 8x8-block grid (D1/ICP.cu:260-261)
+    int br_lo, rows_local;                           // block-row band handled by this launch (row-sharded ICP)
+    int nchain, nwaves;
+    float *chains;                                   // f32[27][512]
+    unsigned int *ticket;
+    float *sums;                                     // f32[27] out
+    int32_t *corr;                                   // optional debug map
+    IcpState *state;                                 // optional: gates the launch / receives the solve
+    const float *pose_state;
+    int do_solve, lvl, iter, max_iter;
+    float thr_alpha, thr_tr;
+    float *trace;
+    long long *timing;                               // optional debug: phase time stamps (wall_clock64, 10 ns ticks)
+};
+
+// Collective over the calling workgroup (>= 2 waves, every thread must call it): wave 1 evaluates the
+// determinant test, thread 0 the Cholesky solve and the pose update.  st = working copy of the state
+// (LDS), out = device-resident state it is committed to, sh = 2 floats of LDS.
+__device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
+                                               int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh);
+
+__global__ __launch_bounds__(64 * ICP_MAX_WAVES)
+void k_icp_iter(IcpIterArgs a) {
+    __shared__ float part[ICP_MAX_WAVES][27];
+    __shared__ float fin[27];
+    __shared__ float solve_sh[2];
+    __shared__ IcpState sst;          // snapshot of the loop state (or of the caller's R, t, intr)
+    __shared__ float spose[24];       // pose_state snapshot for the solve
+    __shared__ int last_flag;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x;
+    const int nblk = a.rows_local * a.grid_cols;
+    const int chain_len = (nblk - t + ICP_CHAINS - 1) / ICP_CHAINS;
+    const int rounds = (chain_len + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES;
+    long long ts0 = a.timing ? wall_clock64() : 0;
+    if (a.timing && t == 0 && threadIdx.x == 0) a.timing[0] = ts0;
+
+    // First memory round trip: the state snapshot (last wave) and round 0's model pixels (all waves)
+    // are requested together; nothing below waits on global memory until the gathers.
+    if (wave == ICP_MAX_WAVES - 1) {
+        float *dst = (float *)&sst;
+        if (a.state) {
+            const float *src = (const float *)a.state;
+            if (lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
+            if (a.pose_state && lane < 24) spose[lane] = a.pose_state[lane];
+        } else {
+            if (lane < 9) sst.Rcurr[lane] = a.R[lane];
+            else if (lane < 12) sst.tcurr[lane - 9] = a.t[lane - 9];
+            else if (lane < 16) sst.intr[lane - 12] = a.intr[lane - 12];
+            else if (lane == 16) { sst.cvg = 0; sst.fail = 0; }
         }
     }
-}
-
-// D1/ICP.cu:50-70 ReduceKernel<<<27, 512>>>
-__global__ __launch_bounds__(512)
-void k_icp_reduce(const float *__restrict__ buf, float *__restrict__ out, int length,
-                  const IcpState *__restrict__ state, int iter) {
-    if (state && (state->fail || (iter > 0 && state->cvg))) return;
-    __shared__ float sm[512];
-    const float *beg = buf + (size_t)blockIdx.x * length;
-    int tid = threadIdx.x;
-    float sum = 0.0f;
-    for (int k = tid; k < length; k += 512) sum += beg[k];
-    sm[tid] = sum;
+    int k = wave;
+    bool active = k < chain_len, inside = false;
+    size_t idx = 0;
+    IcpModelPx mp;
+    auto locate = [&](int kk) {
+        int blk = t + ICP_CHAINS * kk;                // band-local block number, blk = brow + bcol*rows (ICP.cu:238)
+        int br = a.br_lo + blk % a.rows_local, bc = blk / a.rows_local;
+        int i = br * 8 + (lane >> 3), j = bc * 8 + (lane & 7);
+        inside = (i * a.fact < a.n && j * a.fact < a.m);
+        idx = inside ? (size_t)(i * a.fact) * a.m + (size_t)(j * a.fact) : 0;
+    };
+    if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
     __syncthreads();
-    for (int off = 256; off >= 1; off >>= 1) {
-        if (tid < off) sm[tid] = sm[tid] + sm[tid + off];
+    if (sst.fail || (a.iter > 0 && sst.cvg)) return;  // converged / failed earlier: the whole grid leaves
+
+    float acc = 0.0f;                                 // wave 0, lanes 0..26: running chain sum (ICP.cu:56-58)
+    for (int r = 0; r < rounds; r++) {
+        if (r > 0) {
+            k = r * ICP_MAX_WAVES + wave;
+            active = k < chain_len;
+            if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+        }
+        if (active) {
+            IcpRow q;
+#pragma unroll
+            for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
+            IcpProj pr = icp_project(mp, sst.Rcurr, sst.tcurr, sst.intr, a.n, a.m);
+            IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
+            if (inside) {
+                int proj = -1;
+                IcpRow o;
+                bool ok = icp_rows(mp, pr, cu, sst.intr, a.distThres, a.angleThres, o, proj);
+                if (ok) q = o;
+                if (a.corr) a.corr[idx] = ok ? proj : -1;
+            }
+            float v[27];
+            int term = 0;
+#pragma unroll
+            for (int kk = 0; kk < 6; kk++)
+#pragma unroll
+                for (int l = kk; l < 7; l++) v[term++] = q.g[kk] * q.g[l] + q.c[kk] * q.c[l];   // ICP.cu:229
+            bool valid;
+            float sum = fold27(v, lane, term, valid);
+            if (valid && !(lane & 8)) part[wave][term] = sum;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 27) {
+            int cnt = min(ICP_MAX_WAVES, chain_len - r * ICP_MAX_WAVES);
+            for (int w = 0; w < cnt; w++) acc += part[w][lane];
+        }
         __syncthreads();
     }
-    if (tid == 0) out[blockIdx.x] = sm[0];
+    long long ts1 = a.timing ? wall_clock64() : 0;
+    // Publish the chain sums to the other XCDs without a full L2 write-back: agent-scope atomic
+    // stores are written through, the workgroup-scope release only waits for them to complete, and
+    // the last workgroup reads them back with agent-scope atomic loads (each XCD has its own L2).
+    if (wave == 0 && lane < 27)
+        __hip_atomic_store(a.chains + lane * ICP_CHAINS + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    long long ts2 = a.timing ? wall_clock64() : 0;
+    // Two-level arrival counter (same-address device-scope atomics serialise at the memory side):
+    // 16 workgroups share a group counter on its own 128-byte line, the last arrival of a group
+    // bumps the top counter, the last arrival there owns the tail.
+    if (threadIdx.x == 0) {
+        int g = t / ICP_TICKET_GROUP, ngroups = (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP;
+        unsigned int expect = (unsigned int)min(ICP_TICKET_GROUP, a.nchain - g * ICP_TICKET_GROUP);
+        unsigned int old = __hip_atomic_fetch_add(a.ticket + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
+        if (old == expect - 1u) {
+            old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (old == (unsigned int)ngroups - 1u);
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    long long ts3 = a.timing ? wall_clock64() : 0;
+
+    // second stage, tree part (reduce<512>, ICP.cu:28-48): offsets 256,128,64 combine the 8 values a
+    // lane holds (t = lane + 64q), offsets 32..1 are lane shuffles.  Chains beyond nblk hold 0.
+    // Wave w owns terms w, w+8, w+16, w+24; all of its loads are issued before the first add so the
+    // tail costs one memory round trip, not one per term.
+    float x[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int term = wave + ICP_MAX_WAVES * u;
+#pragma unroll
+        for (int qd = 0; qd < 8; qd++) {
+            int tt = lane + 64 * qd;
+            x[u][qd] = (term < 27 && tt < a.nchain)
+                           ? __hip_atomic_load(a.chains + term * ICP_CHAINS + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int term = wave + ICP_MAX_WAVES * u;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) x[u][qd] = x[u][qd] + x[u][qd + 4];
+        x[u][0] = x[u][0] + x[u][2]; x[u][1] = x[u][1] + x[u][3];
+        float s = x[u][0] + x[u][1];
+        s = s + __shfl_down(s, 32);
+        s = s + __shfl_down(s, 16);
+        s = s + __shfl_down(s, 8);
+        s = s + __shfl_down(s, 4);
+        s = s + __shfl_down(s, 2);
+        s = s + __shfl_down(s, 1);
+        if (lane == 0 && term < 27) { fin[term] = s; a.sums[term] = s; }
+    }
+    long long ts4 = a.timing ? wall_clock64() : 0;
+    if (threadIdx.x <= (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) a.ticket[32 * threadIdx.x] = 0u;   // ready for the next launch
+    __syncthreads();
+    if (a.do_solve) icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh);
+    if (a.timing && threadIdx.x == 0) {
+        a.timing[1] = ts0; a.timing[2] = ts1; a.timing[3] = ts2; a.timing[4] = ts3; a.timing[5] = ts4; a.timing[6] = wall_clock64();
+    }
 }
 
 // ---- device-side 6x6 solve and pose update (D1/RG.cpp:851-901) ---------------------------------
@@ -209,56 +382,87 @@ __device__ float d_frob_minus_I(const float *a) {
 }
 __device__ float d_norm3(const float *v) { return __builtin_sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
-__device__ float d_det6(const float *Ain) {
-    float a[36];
-    for (int k = 0; k < 36; k++) a[k] = Ain[k];
+// ---- 6x6 helpers (stand-ins for Eigen's determinant() and llt().solve(), same operation order as
+// the oracle's orc_det6 / orc_llt_solve6) ----------------------------------------------------------
+// A and b come straight from the 27 packed sums (ICP.cu:273-283): (i,j), i <= j <= 6, row-major.
+__device__ __forceinline__ constexpr int tri_idx(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); }
+#define SYM_A(S, i, j) ((S)[tri_idx((i) < (j) ? (i) : (j), (i) < (j) ? (j) : (i))])
+
+// Partial-pivot LU determinant, one matrix ROW per lane (lanes 0..5), columns in registers: no
+// dynamically indexed private arrays (which would live in scratch memory) and no LDS round trips.
+// Pivot search and row exchange are the serial algorithm's, done with lane reads.
+__device__ __forceinline__ float wave_det6(const float *sums, int lane) {
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 6; r++) v = (lane == r) ? SYM_A(sums, r, k) : v;
+        a[k] = v;
+    }
     float det = 1.0f;
+#pragma unroll
     for (int c = 0; c < 6; c++) {
         int p = c;
-        float best = __builtin_fabsf(a[c * 6 + c]);
+        float best = __builtin_fabsf(__shfl(a[c], c));
+#pragma unroll
         for (int r = c + 1; r < 6; r++) {
-            float v = __builtin_fabsf(a[r * 6 + c]);
+            float v = __builtin_fabsf(__shfl(a[c], r));
             if (v > best) { best = v; p = r; }
         }
-        if (p != c) {
-            for (int k = 0; k < 6; k++) { float tmp = a[c * 6 + k]; a[c * 6 + k] = a[p * 6 + k]; a[p * 6 + k] = tmp; }
-            det = -det;
+        float rowp[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            float vp = __shfl(a[k], p), vc = __shfl(a[k], c);
+            rowp[k] = vp;
+            a[k] = (lane == c) ? vp : ((lane == p) ? vc : a[k]);   // exchange rows c and p (no-op when p == c)
         }
-        float piv = a[c * 6 + c];
+        if (p != c) det = -det;
+        float piv = rowp[c];
         det = det * piv;
         if (piv == 0.0f || piv != piv) return det;
-        for (int r = c + 1; r < 6; r++) {
-            float f = a[r * 6 + c] / piv;
-            for (int k = c + 1; k < 6; k++) a[r * 6 + k] = a[r * 6 + k] - f * a[c * 6 + k];
+        if (lane > c && lane < 6) {
+            float f = a[c] / piv;
+#pragma unroll
+            for (int k = c + 1; k < 6; k++) a[k] = a[k] - f * rowp[k];
         }
     }
     return det;
 }
-__device__ int d_llt_solve6(const float *A, const float *b, float *x) {
-    float L[36];
-    for (int k = 0; k < 36; k++) L[k] = 0.0f;
+
+// Row Cholesky + forward/backward substitution, fully unrolled in registers.  Returns 1 on a
+// non-positive pivot.
+__device__ __forceinline__ int llt_solve6_reg(const float *sums, float *x) {
+    float L[6][6], y[6];
+#pragma unroll
     for (int k = 0; k < 6; k++) {
-        float s = A[k * 6 + k];
-        for (int p = 0; p < k; p++) s = s - L[k * 6 + p] * L[k * 6 + p];
+        float s = SYM_A(sums, k, k);
+#pragma unroll
+        for (int p = 0; p < k; p++) s = s - L[k][p] * L[k][p];
         if (!(s > 0.0f)) return 1;
         float lkk = __builtin_sqrtf(s);
-        L[k * 6 + k] = lkk;
+        L[k][k] = lkk;
+#pragma unroll
         for (int r = k + 1; r < 6; r++) {
-            float v = A[r * 6 + k];
-            for (int p = 0; p < k; p++) v = v - L[r * 6 + p] * L[k * 6 + p];
-            L[r * 6 + k] = v / lkk;
+            float v = SYM_A(sums, r, k);
+#pragma unroll
+            for (int p = 0; p < k; p++) v = v - L[r][p] * L[k][p];
+            L[r][k] = v / lkk;
         }
     }
-    float y[6];
+#pragma unroll
     for (int r = 0; r < 6; r++) {
-        float v = b[r];
-        for (int p = 0; p < r; p++) v = v - L[r * 6 + p] * y[p];
-        y[r] = v / L[r * 6 + r];
+        float v = sums[tri_idx(r, 6)];
+#pragma unroll
+        for (int p = 0; p < r; p++) v = v - L[r][p] * y[p];
+        y[r] = v / L[r][r];
     }
+#pragma unroll
     for (int r = 5; r >= 0; r--) {
         float v = y[r];
-        for (int p = r + 1; p < 6; p++) v = v - L[p * 6 + r] * x[p];
-        x[r] = v / L[r * 6 + r];
+#pragma unroll
+        for (int p = r + 1; p < 6; p++) v = v - L[p][r] * x[p];
+        x[r] = v / L[r][r];
     }
     return 0;
 }
@@ -283,25 +487,9 @@ __global__ void k_icp_begin(IcpState *st, const float *pose_state, CalibV c, int
     status[0] = 0; status[1] = 0;
 }
 
-__global__ void k_icp_solve(IcpState *st, const float *__restrict__ sums, const float *pose_state, int lvl, int iter,
-                            int max_iter, float thr_alpha, float thr_tr, float *trace) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->fail || (iter > 0 && st->cvg)) return;
-    float A[36], b[6], x[6];
-    int sh = 0;
-    for (int i = 0; i < 6; i++)
-        for (int j = i; j < 7; j++) {                          // ICP.cu:273-283
-            float v = sums[sh++];
-            if (j == 6) b[i] = v; else { A[j * 6 + i] = v; A[i * 6 + j] = v; }
-        }
-    float det = d_det6(A);                                     // RG.cpp:862
-    if ((double)__builtin_fabsf(det) < 1e-15 || det != det) { st->fail = 1; return; }
-    if (d_llt_solve6(A, b, x)) { st->fail = 1; return; }
-    if (trace) {
-        float *tr = trace + 33 * st->iters;
-        for (int k = 0; k < 27; k++) tr[k] = sums[k];
-        for (int k = 0; k < 6; k++) tr[27 + k] = x[k];
-    }
+// pose update of RG.cpp:874-889 for a solved increment x; st is a thread-private copy
+__device__ __forceinline__ void icp_pose_update(IcpState *st, const float *x, const float *pose_state, int lvl, int iter,
+                                                int max_iter, float thr_alpha, float thr_tr) {
     st->iters = st->iters + 1;
     st->lvl_iters = st->lvl_iters + (1 << (8 * lvl));
     double q[4];
@@ -334,6 +522,55 @@ __global__ void k_icp_solve(IcpState *st, const float *__restrict__ sums, const 
     if (!cvg || lvl > 0) d_set_rt_curr(st, pose_state);
 }
 
+__device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
+                                               int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float x[6];
+    int llt_fail = 0;
+    if (wave == 1) {
+        float det = wave_det6(sums, lane);                     // RG.cpp:862, concurrently with the solve
+        if (lane == 0) sh[0] = det;
+    } else if (threadIdx.x == 0) {
+        llt_fail = llt_solve6_reg(sums, x);                    // RG.cpp:873
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    IcpState loc = *st;
+    float det = sh[0];
+    if ((double)__builtin_fabsf(det) < 1e-15 || det != det || llt_fail) {   // RG.cpp:864-871
+        loc.fail = 1;
+    } else {
+        if (trace) {
+            float *tr = trace + 33 * loc.iters;
+            for (int k = 0; k < 27; k++) tr[k] = sums[k];
+            for (int k = 0; k < 6; k++) tr[27 + k] = x[k];
+        }
+        icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
+    }
+    *out = loc;
+}
+
+// stand-alone solve for the row-sharded path (launch with 128 threads): sums = sum over `parts`
+// gathered 27-float partial systems, in rank order
+__global__ __launch_bounds__(128)
+void k_icp_solve(IcpState *st, const float *__restrict__ gathered, int parts, const float *pose_state, int lvl,
+                 int iter, int max_iter, float thr_alpha, float thr_tr, float *trace) {
+    __shared__ float sums[27];
+    __shared__ float sh[2];
+    __shared__ IcpState sst;
+    __shared__ float spose[24];
+    if (threadIdx.x < sizeof(IcpState) / 4) ((int *)&sst)[threadIdx.x] = ((const int *)st)[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) spose[threadIdx.x - 64] = pose_state[threadIdx.x - 64];
+    if (threadIdx.x < 27) {
+        float s = gathered[threadIdx.x];
+        for (int p = 1; p < parts; p++) s = s + gathered[27 * p + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (sst.fail || (iter > 0 && sst.cvg)) return;
+    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh);
+}
+
 __global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     status[1] = st->iters;
@@ -355,13 +592,15 @@ __global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status) {
 static int div_up(int x, int y) { return (x % y) ? ((x + y - 1) / y) : (x / y); }
 
 extern "C" int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid_cols) {
+    // The reference sizes buf_dev by the 8x8-block grid (27*n*m floats, ICP.cu:10); here the first
+    // reduction stage never leaves the chip, so the scratch is 27 x 512 chain sums whatever the image size.
     if (!ctx || grid_rows <= 0 || grid_cols <= 0) return RGBDSLAM_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    size_t blocks = (size_t)grid_rows * grid_cols;
-    if (ctx->buf_dev && ctx->buf_blocks >= blocks) return 0;
-    if (ctx->buf_dev) { HIP_TRY(hipFree(ctx->buf_dev)); ctx->buf_dev = nullptr; }
-    HIP_TRY(hipMalloc((void **)&ctx->buf_dev, 27 * blocks * sizeof(float)));
-    ctx->buf_blocks = blocks;
+    if (!ctx->buf_dev) HIP_TRY(hipMalloc((void **)&ctx->buf_dev, 27 * ICP_CHAINS * sizeof(float)));
+    if (!ctx->ticket_dev) {
+        HIP_TRY(hipMalloc((void **)&ctx->ticket_dev, ICP_TICKET_WORDS * sizeof(unsigned int)));
+        HIP_TRY(hipMemset(ctx->ticket_dev, 0, ICP_TICKET_WORDS * sizeof(unsigned int)));
+    }
     if (!ctx->outbuf_dev) HIP_TRY(hipMalloc((void **)&ctx->outbuf_dev, 27 * sizeof(float)));
     if (!ctx->out_host) HIP_TRY(hipHostMalloc((void **)&ctx->out_host, 27 * sizeof(float), hipHostMallocDefault));
     if (!ctx->icp_state) HIP_TRY(hipMalloc((void **)&ctx->icp_state, sizeof(IcpState)));
@@ -370,25 +609,46 @@ extern "C" int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid
 
 extern "C" int rgbdslam_free_buffers(rgbdslam_ctx *ctx) {
     if (!ctx) return RGBDSLAM_E_ARG;
-    if (ctx->buf_dev) { (void)hipFree(ctx->buf_dev); ctx->buf_dev = nullptr; ctx->buf_blocks = 0; }
+    if (ctx->buf_dev) { (void)hipFree(ctx->buf_dev); ctx->buf_dev = nullptr; }
+    if (ctx->ticket_dev) { (void)hipFree(ctx->ticket_dev); ctx->ticket_dev = nullptr; }
     if (ctx->outbuf_dev) { (void)hipFree(ctx->outbuf_dev); ctx->outbuf_dev = nullptr; }
     if (ctx->out_host) { (void)hipHostFree(ctx->out_host); ctx->out_host = nullptr; }
     if (ctx->icp_state) { (void)hipFree(ctx->icp_state); ctx->icp_state = nullptr; }
     return 0;
 }
 
-static int launch_system(rgbdslam_ctx *ctx, const float *intr, const float *R, const float *t, const float *VMap,
-                         const float *NMap, const float *RGB, const float *Gx, size_t gxp, const float *Gy, size_t gyp,
-                         const float *VMap_prev, const float *NMap_prev, const float *RGB_prev, float distThres,
-                         float angleThres, int n, int m, int fact, int32_t *corr, const IcpState *state, int iter) {
+struct IcpMaps {
+    const float *VMap, *NMap, *RGB, *Gx, *Gy;
+    size_t gxp, gyp;
+    const float *VMap_prev, *NMap_prev, *RGB_prev;
+};
+
+// One launch of k_icp_iter over block rows [br_lo, br_hi) of the level's 8x8-block grid.
+static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, const float *t, const IcpMaps &mp,
+                       float distThres, float angleThres, int n, int m, int fact, int br_lo, int br_hi, float *sums,
+                       int32_t *corr, IcpState *state, const float *pose_state, int do_solve, int lvl, int iter, int max_iter,
+                       float thr_alpha, float thr_tr, float *trace) {
     int gr = div_up(n / fact, 8), gc = div_up(m / fact, 8);   // D1/ICP.cu:260-261
     if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
-    if (!ctx->buf_dev || ctx->buf_blocks < (size_t)gr * gc) return RGBDSLAM_E_STATE;
-    dim3 grid((gc + ICP_WAVES - 1) / ICP_WAVES, gr);
-    KLAUNCH(ctx, k_icp_match, grid, dim3(64 * ICP_WAVES), intr, R, t, VMap, NMap, RGB, Gx, gxp,
-                       Gy, gyp, VMap_prev, NMap_prev, RGB_prev, distThres, angleThres, n, m, fact, gr, gc, ctx->buf_dev,
-                       corr, state, iter);
-    KLAUNCH(ctx, k_icp_reduce, dim3(27), dim3(512), ctx->buf_dev, ctx->outbuf_dev, gr * gc, state, iter);
+    if (br_lo < 0) br_lo = 0;
+    if (br_hi > gr) br_hi = gr;
+    if (br_hi <= br_lo) return RGBDSLAM_E_ARG;
+    if (!ctx->buf_dev || !ctx->ticket_dev) return RGBDSLAM_E_STATE;
+    IcpIterArgs a;
+    a.intr = intr; a.R = R; a.t = t;
+    a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
+    a.VMap_prev = mp.VMap_prev; a.NMap_prev = mp.NMap_prev; a.RGBD_prev = mp.RGB_prev;
+    a.distThres = distThres; a.angleThres = angleThres;
+    a.n = n; a.m = m; a.fact = fact; a.grid_rows = gr; a.grid_cols = gc;
+    a.br_lo = br_lo; a.rows_local = br_hi - br_lo;
+    long nblk = (long)a.rows_local * gc;
+    a.nchain = (int)(nblk < ICP_CHAINS ? nblk : ICP_CHAINS);
+    a.nwaves = ICP_MAX_WAVES;   // always 8 waves: the last workgroup needs them for the 27-term tail
+    a.chains = ctx->buf_dev; a.ticket = ctx->ticket_dev; a.sums = sums; a.corr = corr;
+    a.state = state; a.pose_state = pose_state; a.do_solve = do_solve; a.lvl = lvl; a.iter = iter; a.max_iter = max_iter;
+    a.thr_alpha = thr_alpha; a.thr_tr = thr_tr; a.trace = trace;
+    a.timing = ctx->icp_timing_dev;
+    KLAUNCH(ctx, k_icp_iter, dim3(a.nchain), dim3(64 * a.nwaves), a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -405,8 +665,9 @@ extern "C" int rgbdslam_estimate_system_gauss_newton(rgbdslam_ctx *ctx, const fl
         return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || fact <= 0 || gxp < 4 * (size_t)m || gyp < 4 * (size_t)m) return RGBDSLAM_E_ARG;
     if (corr_dev) HIP_TRY(hipMemsetAsync(corr_dev, 0xFF, sizeof(int32_t) * (size_t)n * m, ctx->stream));
-    int rc = launch_system(ctx, intr_dev, Rcurr_dev, tcurr_dev, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev, NMap_prev,
-                           RGB_prev, distThres, angleThres, n, m, fact, corr_dev, nullptr, 0);
+    IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
+    int rc = launch_iter(ctx, intr_dev, Rcurr_dev, tcurr_dev, mp, distThres, angleThres, n, m, fact, 0, 1 << 30,
+                         ctx->outbuf_dev, corr_dev, nullptr, nullptr, 0, 0, 0, 0, 0.0f, 0.0f, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->out_host, ctx->outbuf_dev, 27 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -420,6 +681,12 @@ extern "C" int rgbdslam_estimate_system_gauss_newton(rgbdslam_ctx *ctx, const fl
     return 0;
 }
 
+static int check_align_args(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, int n, int m, size_t gxp, size_t gyp) {
+    if (n <= 0 || m <= 0 || prm->lvl < 1 || prm->lvl > 3 || gxp < 4 * (size_t)m || gyp < 4 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib || !ctx->icp_state) return RGBDSLAM_E_STATE;
+    return 0;
+}
+
 extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap,
                                            const float *NMap, const float *RGB, const float *Gx, size_t gxp,
                                            const float *Gy, size_t gyp, const float *VMap_prev, const float *NMap_prev,
@@ -428,23 +695,68 @@ extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp
     if (!ctx || !prm || !VMap || !NMap || !RGB || !Gx || !Gy || !VMap_prev || !NMap_prev || !RGB_prev ||
         !pose_state_dev || !status_dev)
         return RGBDSLAM_E_ARG;
-    if (n <= 0 || m <= 0 || prm->lvl < 1 || prm->lvl > 3 || gxp < 4 * (size_t)m || gyp < 4 * (size_t)m) return RGBDSLAM_E_ARG;
-    if (!ctx->have_calib || !ctx->icp_state) return RGBDSLAM_E_STATE;
+    int rc = check_align_args(ctx, prm, n, m, gxp, gyp);
+    if (rc) return rc;
     IcpState *st = ctx->icp_state;
+    IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
     KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
     int fact = 1 << (prm->lvl - 1);                            // RG.cpp:832
     for (int lvl = prm->lvl - 1; lvl > -1; lvl--) {
         int n_it = prm->max_iter[lvl] + 2;                     // iter = 0 .. max_iter+1 (RG.cpp:889)
         for (int iter = 0; iter < n_it; iter++) {
-            int rc = launch_system(ctx, st->intr, st->Rcurr, st->tcurr, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev,
-                                   NMap_prev, RGB_prev, prm->distThres, prm->angleThres, n, m, fact, nullptr, st, iter);
+            rc = launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, fact, 0, 1 << 30,
+                             ctx->outbuf_dev, nullptr, st, pose_state_dev, 1, lvl, iter, prm->max_iter[lvl],
+                             prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev);
             if (rc) return rc;
-            KLAUNCH(ctx, k_icp_solve, dim3(1), dim3(64), st, ctx->outbuf_dev, pose_state_dev, lvl, iter,
-                               prm->max_iter[lvl], prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev);
         }
         fact /= 2;
     }
     KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- row-sharded Gauss-Newton loop (BASELINE configs[3]): the caller interleaves a
+// collective between band_system and solve_gathered; everything stays stream-ordered. ------------
+extern "C" int rgbdslam_align_begin(rgbdslam_ctx *ctx, const float *pose_state_dev, int32_t *status_dev) {
+    if (!ctx || !pose_state_dev || !status_dev) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib || !ctx->icp_state) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), ctx->icp_state, pose_state_dev, ctx->calib, status_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_align_band_system(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap,
+                                          const float *NMap, const float *RGB, const float *Gx, size_t gxp, const float *Gy,
+                                          size_t gyp, const float *VMap_prev, const float *NMap_prev, const float *RGB_prev,
+                                          int n, int m, int lvl, int iter, int block_row_lo, int block_row_hi,
+                                          float *sums27_dev) {
+    if (!ctx || !prm || !VMap || !NMap || !RGB || !Gx || !Gy || !VMap_prev || !NMap_prev || !RGB_prev || !sums27_dev)
+        return RGBDSLAM_E_ARG;
+    int rc = check_align_args(ctx, prm, n, m, gxp, gyp);
+    if (rc) return rc;
+    if (lvl < 0 || lvl >= prm->lvl || iter < 0) return RGBDSLAM_E_ARG;
+    IcpState *st = ctx->icp_state;
+    IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
+    return launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, 1 << lvl, block_row_lo,
+                       block_row_hi, sums27_dev, nullptr, st, nullptr, 0, lvl, iter, prm->max_iter[lvl], 0.0f, 0.0f, nullptr);
+}
+
+extern "C" int rgbdslam_align_solve_gathered(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *gathered_dev,
+                                             int parts, const float *pose_state_dev, int lvl, int iter, float *trace_dev) {
+    if (!ctx || !prm || !gathered_dev || parts <= 0 || !pose_state_dev || lvl < 0 || lvl >= prm->lvl || iter < 0)
+        return RGBDSLAM_E_ARG;
+    if (!ctx->icp_state) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_icp_solve, dim3(1), dim3(128), ctx->icp_state, gathered_dev, parts, pose_state_dev, lvl, iter,
+            prm->max_iter[lvl], prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int32_t *status_dev) {
+    if (!ctx || !pose_state_dev || !status_dev) return RGBDSLAM_E_ARG;
+    if (!ctx->icp_state) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), ctx->icp_state, pose_state_dev, status_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

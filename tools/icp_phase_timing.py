@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Prints the phase breakdown of the ICP iteration kernel (debug hook rgbdslam_debug_icp_timing)."""
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("rgb-d-slam_amd"); synth = importlib.import_module("rgb-d-slam_amd.synth")
+n, m = 480, 640
+calib = synth.calib_for(n, m)
+ctx = pkg.Context(0); ctx.set_calibration_matrix(calib)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+maps = []
+for R, t in [(np.eye(3), np.zeros(3)), synth.pair_offset_pose()]:
+    d, c = synth.render(R, t, n, m, calib, noise_sigma=0.001)
+    v = torch.empty(n, m, 3, device="cuda"); nm = torch.empty(n, m, 3, device="cuda"); rgb = torch.empty(n, m, 3, device="cuda")
+    dd = dev(d); ctx.vertex_map_kinect(v, dd, 2 * m, n, m); ctx.gpu_cpy_char3(dev(c), 3 * m, rgb, n, m); ctx.compute_normal(nm, v, n, m, True)
+    maps.append((v, nm, rgb, dd))
+rgbd0 = torch.empty(n, m, 4, device="cuda"); ctx.gpu_add_zbuff_off(maps[0][3], 2 * m, maps[0][2], rgbd0, n, m)
+gx = torch.empty(n, m, device="cuda"); gy = torch.empty(n, m, device="cuda"); ctx.intensity_sobel(maps[1][2], None, gx, gy, n, m)
+ctx.alloc_buffers(60, 80)
+timing = torch.zeros(7, dtype=torch.int64, device="cuda")
+ctx.lib.rgbdslam_debug_icp_timing(ctx._h, C.c_void_p(timing.data_ptr()))
+I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+Rd, td, intr = dev(I), dev(z), dev(calib[:4])
+for fact in (4, 2, 1):
+    acc = np.zeros(6)
+    for rep in range(20):
+        ctx.estimate_system(Rd, td, maps[1][0], maps[1][1], maps[1][2], gx, gy, maps[0][0], maps[0][1], rgbd0, intr, 0.05, 0.342, n, m, fact)
+        ts = timing.cpu().numpy().astype(np.int64)
+        if rep >= 5: acc += np.diff(ts[[0, 1, 2, 3, 4, 5, 6]]) * 10.0 / 15
+    print("fact %d: tail-WG start after first WG %6.0f ns | rounds %6.0f | publish %6.0f | ticket %6.0f | tree %6.0f | solve/end %6.0f | total %6.0f ns"
+          % (fact, *acc, acc.sum()))
+# with the solve: device-resident loop, stamps of the LAST launch (level 0, last iteration)
+state = dev(np.concatenate([I, z, I, z]).astype(np.float32)); status = torch.zeros(4, dtype=torch.int32, device="cuda")
+acc = np.zeros(6)
+for rep in range(20):
+    state.copy_(dev(np.concatenate([I, z, I, z]).astype(np.float32)))
+    ctx.align_gauss_newton(pkg.icp_params(), maps[1][0], maps[1][1], maps[1][2], gx, gy, maps[0][0], maps[0][1], rgbd0, n, m, state, status)
+    ts = timing.cpu().numpy().astype(np.int64)
+    if rep >= 5: acc += np.diff(ts) * 10.0 / 15
+print("loop, last launch (fact 1, with solve): start %6.0f | rounds %6.0f | publish %6.0f | ticket %6.0f | tree %6.0f | solve %6.0f | total %6.0f ns; iters %d"
+      % (*acc, acc.sum(), int(status[1])))
