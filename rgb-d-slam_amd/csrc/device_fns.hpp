@@ -1,0 +1,292 @@
+// device_fns.hpp -- per-pixel device functions shared by the per-operator kernels (preprocess.hip,
+// predict.hip) and the fused frame kernels (frame.hip).  One definition of each formula, so both
+// launch shapes produce bit-identical results.
+#pragma once
+#include "common.hpp"
+
+// ---- D1/Kernel.cu:33-52 VertexMapKinectKernel: vertex of pixel (i, j) from raw depth d -----------
+__device__ __forceinline__ F3 vertex_from_depth(uint16_t d, int i, int j, const CalibV &c) {
+    F3 r; r.x = r.y = r.z = 0.0f;
+    if (d == 0) return r;
+    float s = c.v[9] / c.v[10];
+    float fd = (float)d;
+    float sd = s * fd;
+    r.x = sd * (((float)j - c.v[2]) / c.v[0]);
+    r.y = sd * (((float)i - c.v[3]) / c.v[1]);
+    r.z = (-s) * fd;
+    return r;
+}
+
+// ---- D1/Kernel.cu:123-307 NormalKernel ------------------------------------------------------------
+// one of the four triangles around the pixel: normalised cross((a-p),(b-p)); returns 1 if counted
+__device__ __forceinline__ int tri_normal(F3 p, F3 a, F3 b, F3 &o) {
+    o.x = o.y = o.z = 0.0f;
+    if (a.z != 0.0f && b.z != 0.0f) {
+        float ax = a.x - p.x, ay = a.y - p.y, az = a.z - p.z;
+        float bx = b.x - p.x, by = b.y - p.y, bz = b.z - p.z;
+        float cx = ay * bz - az * by;
+        float cy = az * bx - ax * bz;
+        float cz = ax * by - ay * bx;
+        float nn = (cx * cx + cy * cy + cz * cz);
+        o.x = cx; o.y = cy; o.z = cz;
+        if (nn != 0.0f) {
+            float r = __builtin_sqrtf(nn);
+            o.x = cx / r; o.y = cy / r; o.z = cz / r;
+            return 1;
+        }
+    }
+    return 0;
+}
+// normal of an interior pixel p (z != 0) from its 4-neighbourhood: dn = (i+1,j), up = (i-1,j), rt = (i,j+1), lf = (i,j-1)
+__device__ __forceinline__ F3 normal_from_cross(F3 p, F3 dn, F3 up, F3 rt, F3 lf, int inverse) {
+    F3 z; z.x = z.y = z.z = 0.0f;
+    F3 n1, n2, n3, n4;
+    int tot = tri_normal(p, dn, rt, n1);
+    tot += tri_normal(p, rt, up, n2);
+    tot += tri_normal(p, up, lf, n3);
+    tot += tri_normal(p, lf, dn, n4);
+    if (tot == 0) return z;
+    float ft = (float)tot;
+    float a0 = (((n1.x + n2.x) + n3.x) + n4.x) / ft;
+    float a1 = (((n1.y + n2.y) + n3.y) + n4.y) / ft;
+    float a2 = (((n1.z + n2.z) + n3.z) + n4.z) / ft;
+    float nn = __builtin_sqrtf((a0 * a0 + a1 * a1) + a2 * a2);
+    if (nn == 0.0f) return z;
+    F3 r;
+    if (inverse) { r.x = (-a0) / nn; r.y = (-a1) / nn; r.z = (-a2) / nn; }
+    else { r.x = a0 / nn; r.y = a1 / nn; r.z = a2 / nn; }
+    return r;
+}
+__device__ __forceinline__ F3 normal_global(const float *__restrict__ VMap, int i, int j, int n, int m, int inverse) {
+    size_t idx = (size_t)i * m + j;
+    F3 p = ld3(VMap, idx);
+    F3 z; z.x = z.y = z.z = 0.0f;
+    if (i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f) return z;
+    return normal_from_cross(p, ld3(VMap, idx + m), ld3(VMap, idx - m), ld3(VMap, idx + 1), ld3(VMap, idx - 1), inverse);
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// ---- D1/Kernel.cu:440-526 MergeDepthOffKernel: new (.w, mask) of one pixel -------------------------
+// returns the new .w; newmask < 0 = mask unchanged
+__device__ __forceinline__ float merge_pixel(float w_old, uint16_t d, uint8_t mask_old, const CalibV &c, int &newmask) {
+    float ds = c.v[9], factor = c.v[10];
+    float dv = (ds / factor) * (float)d;
+    float dp = (float)((double)w_old * SLAM_MAX_DEPTH);
+    float mv = (float)((double)(float)mask_old - 10.0);
+    const float mt = 1.0f;
+    float w = w_old;
+    newmask = -1;
+    if ((double)dv < 0.1) {
+    } else if ((double)dp < 0.1 || __builtin_fabs((double)mv + 9.0) < 0.01) {
+        w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
+    } else if ((double)dv < ((double)dp - SLAM_MAXTOLERANCE)) {
+        w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
+    } else {
+        double mx = 1.0 > 1.0 * (double)dv ? 1.0 : 1.0 * (double)dv;
+        if ((double)dv > ((double)dp + mx * SLAM_MAXTOLERANCE)) {
+            newmask = 10;
+        } else {
+            float am = __builtin_fabsf(mv);
+            float avg = (dv * mt + am * dp) / (mt + am);
+            w = (float)((double)avg / SLAM_MAX_DEPTH);
+            double mk = (double)(mt + am) + 10.0;
+            if (mk > 255.0) mk = 255.0;
+            newmask = (int)(uint8_t)mk;
+        }
+    }
+    return w;
+}
+
+// ---- D1/Kernel.cu:54-72 VertexMapGLKernel -----------------------------------------------------------
+__device__ __forceinline__ F3 vertex_from_w(float w, int i, int j, const CalibV &c) {
+    double z = (double)w * SLAM_MAX_DEPTH;
+    F3 r;
+    r.x = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)j - c.v[2]) / c.v[0]));
+    r.y = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)i - c.v[3]) / c.v[1]));
+    r.z = (float)((double)(-w) * SLAM_MAX_DEPTH);
+    return r;
+}
+
+// ---- D1/Kernel.cu:783-802 AddZBUFFOffKernel: .w of the seeded model ---------------------------------
+__device__ __forceinline__ float zbuff_w(uint16_t d, const CalibV &c) {
+    float z = (c.v[9] / c.v[10]) * (float)d;
+    return ((double)z > SLAM_MAX_DEPTH || (double)z < 0.0) ? 0.0f : (float)((double)z / SLAM_MAX_DEPTH);
+}
+
+// ---- D1/Kernel.cu:345-379 TransformVertexMapKernel: .w written next to a transformed vertex ---------
+__device__ __forceinline__ float depth_attr(float z) {
+    return ((double)(-z) > SLAM_MAX_DEPTH || (double)(-z) < 0.0) ? 0.0f : (float)((double)(-z) / SLAM_MAX_DEPTH);
+}
+
+// ---- D1/Kernel.cu:381-438 QuadTrimFrameKernel --------------------------------------------------------
+__device__ __forceinline__ float dist3(F3 a, F3 b) {
+    float x = a.x - b.x, y = a.y - b.y, z = a.z - b.z;
+    return __builtin_sqrtf((x * x + y * y) + z * z);
+}
+__device__ __forceinline__ bool quad_trimmed(F3 a, F3 b, F3 c, F3 d, float thresh) {
+    float mx = fmaxf(dist3(a, b), dist3(a, c));
+    mx = fmaxf(dist3(a, d), mx);
+    mx = fmaxf(dist3(b, c), mx);
+    mx = fmaxf(dist3(b, d), mx);
+    mx = fmaxf(dist3(c, d), mx);
+    return mx > thresh;
+}
+
+// ---- compute rasteriser ---------------------------------------------------------------
+// Vertices are snapped to 1/256 pixel; coverage uses exact 64-bit integer edge functions with a
+// top-left rule (watertight, each pixel of a shared edge drawn once); depth and attributes are
+// interpolated perspective-correctly in double; the z-buffer is a u64 atomicMin on
+// (f32 depth bits << 32 | ~triangle id): nearest wins, the later primitive wins ties (GL_LEQUAL).
+#define RASTER_MIN_DEPTH 1e-3f
+#define RASTER_GUARD 16384.0f
+#define ZBUF_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct RasTri { int X[3], Y[3]; double inv_d[3]; long long area; int order[3]; };
+
+__device__ __forceinline__ bool ras_setup(const F3 *vtx, const CalibV &c, RasTri &T) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        F3 v = vtx[k];
+        float dk = -v.z;
+        if (!(dk >= RASTER_MIN_DEPTH)) return false;
+        float u = (v.x / dk) * c.v[0] + c.v[2];
+        float w = (v.y / dk) * c.v[1] + c.v[3];
+        if (!(__builtin_fabsf(u) <= RASTER_GUARD) || !(__builtin_fabsf(w) <= RASTER_GUARD)) return false;
+        T.X[k] = f2i_rn(u * 256.0f);
+        T.Y[k] = f2i_rn(w * 256.0f);
+        T.inv_d[k] = 1.0 / (double)dk;
+        T.order[k] = k;
+    }
+    long long area = (long long)(T.X[1] - T.X[0]) * (T.Y[2] - T.Y[0]) - (long long)(T.Y[1] - T.Y[0]) * (T.X[2] - T.X[0]);
+    if (area == 0) return false;
+    if (area < 0) {
+        int t;
+        t = T.X[1]; T.X[1] = T.X[2]; T.X[2] = t;
+        t = T.Y[1]; T.Y[1] = T.Y[2]; T.Y[2] = t;
+        double dd = T.inv_d[1]; T.inv_d[1] = T.inv_d[2]; T.inv_d[2] = dd;
+        T.order[1] = 2; T.order[2] = 1;
+        area = -area;
+    }
+    T.area = area;
+    return true;
+}
+__device__ __forceinline__ long long ras_edge(int ax, int ay, int bx, int by, int px, int py) {
+    return (long long)(bx - ax) * (py - ay) - (long long)(by - ay) * (px - ax);
+}
+__device__ __forceinline__ bool ras_topleft(int ax, int ay, int bx, int by) {
+    int dx = bx - ax, dy = by - ay;
+    return (dy < 0) || (dy == 0 && dx < 0);
+}
+__device__ __forceinline__ bool ras_cover(const RasTri &T, int px, int py, long long *w) {
+    int PX = px * 256, PY = py * 256;
+    w[0] = ras_edge(T.X[1], T.Y[1], T.X[2], T.Y[2], PX, PY);
+    w[1] = ras_edge(T.X[2], T.Y[2], T.X[0], T.Y[0], PX, PY);
+    w[2] = ras_edge(T.X[0], T.Y[0], T.X[1], T.Y[1], PX, PY);
+    if (w[0] < 0 || w[1] < 0 || w[2] < 0) return false;
+    if (w[0] == 0 && !ras_topleft(T.X[1], T.Y[1], T.X[2], T.Y[2])) return false;
+    if (w[1] == 0 && !ras_topleft(T.X[2], T.Y[2], T.X[0], T.Y[0])) return false;
+    if (w[2] == 0 && !ras_topleft(T.X[0], T.Y[0], T.X[1], T.Y[1])) return false;
+    return true;
+}
+// z-buffer pass for one triangle
+__device__ __forceinline__ void ras_draw(unsigned long long *__restrict__ zbuf, const F3 *vtx, uint32_t tri_id,
+                                         const CalibV &c, float znear, float zfar, int n, int m) {
+    RasTri T;
+    if (!ras_setup(vtx, c, T)) return;
+    int xmn = min(T.X[0], min(T.X[1], T.X[2])), xmx = max(T.X[0], max(T.X[1], T.X[2]));
+    int ymn = min(T.Y[0], min(T.Y[1], T.Y[2])), ymx = max(T.Y[0], max(T.Y[1], T.Y[2]));
+    int x0 = max(0, (xmn + 255) >> 8), x1 = min(m - 1, xmx >> 8);
+    int y0 = max(0, (ymn + 255) >> 8), y1 = min(n - 1, ymx >> 8);
+    for (int py = y0; py <= y1; py++)
+        for (int px = x0; px <= x1; px++) {
+            long long w[3];
+            if (!ras_cover(T, px, py, w)) continue;
+            double W = ((double)w[0] * T.inv_d[0] + (double)w[1] * T.inv_d[1]) + (double)w[2] * T.inv_d[2];
+            float dpx = (float)((double)T.area / W);
+            if (!(dpx >= znear) || !(dpx <= zfar)) continue;
+            unsigned long long key = ((unsigned long long)__float_as_uint(dpx) << 32) | (unsigned long long)(0xFFFFFFFFu - tri_id);
+            atomicMin(&zbuf[(size_t)py * m + px], key);
+        }
+}
+// resolve pass for the pixel (px, py) covered by triangle vtx with attributes att (r, g, b, depth/100)
+__device__ __forceinline__ float4 ras_shade(const F3 *vtx, const float4 *att, const CalibV &c, int px, int py) {
+    RasTri T; long long w[3];
+    ras_setup(vtx, c, T);
+    ras_cover(T, px, py, w);
+    double b0 = (double)w[0] * T.inv_d[0], b1 = (double)w[1] * T.inv_d[1], b2 = (double)w[2] * T.inv_d[2];
+    double W = (b0 + b1) + b2;
+    // T.order is a permutation of {0,1,2}: select without dynamic indexing
+    float4 A0 = att[0], A1 = (T.order[1] == 1) ? att[1] : att[2], A2 = (T.order[1] == 1) ? att[2] : att[1];
+    float4 o;
+    o.x = (float)(((b0 * (double)A0.x + b1 * (double)A1.x) + b2 * (double)A2.x) / W);
+    o.y = (float)(((b0 * (double)A0.y + b1 * (double)A1.y) + b2 * (double)A2.y) / W);
+    o.z = (float)(((b0 * (double)A0.z + b1 * (double)A1.z) + b2 * (double)A2.z) / W);
+    o.w = (float)(((b0 * (double)A0.w + b1 * (double)A1.w) + b2 * (double)A2.w) / W);
+    return o;
+}
+__device__ __forceinline__ void quad_vertex_ids(uint32_t q, const uint32_t *__restrict__ index, int m, uint32_t *id) {
+    if (index) {
+        uint4 v = *(const uint4 *)(index + 4 * (size_t)q);
+        id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+    } else {
+        uint32_t i = q / (uint32_t)(m - 1), j = q % (uint32_t)(m - 1);
+        id[0] = i * m + j; id[1] = id[0] + 1; id[2] = id[0] + m + 1; id[3] = id[0] + m;
+    }
+}
+
+// ---- D1/Kernel.cu:309-343 ReadKernel: texel -> vertex ----------------------------------------------
+__device__ __forceinline__ F3 vertex_from_texel(float w, int i, int j, const CalibV &c) {
+    float z = (float)((double)w * SLAM_MAX_DEPTH);
+    F3 r;
+    r.x = z * (((float)j - c.v[2]) / c.v[0]);
+    r.y = z * (((float)i - c.v[3]) / c.v[1]);
+    r.z = -z;
+    return r;
+}
+
+// ---- D1/Kernel.cu:634-667 ProjectMaskKernel: source pixel of the gather, -1 = out of view -----------
+__device__ __forceinline__ long project_source(const float *P, const CalibV &c, F3 v, int n, int m) {
+    if (is_zero3(v)) return -1;
+    F3 r = xf_point(P, v);
+    float az = __builtin_fabsf(r.z);
+    int pu = f2i_rn((r.x / az) * c.v[0] + c.v[2]);
+    int pv = f2i_rn((r.y / az) * c.v[1] + c.v[3]);
+    // the reference only tests the upper bounds; negative projections are defined as out of view
+    if (pv > n - 1 || pu > m - 1 || pv < 0 || pu < 0) return -1;
+    return (long)pv * m + pu;
+}
+
+// ---- D1/RG.cu:252-320 SegmentKernel: label adopted by an unlabeled pixel (0 = none) ------------------
+__device__ __forceinline__ uint8_t segment_pixel(const uint8_t *__restrict__ in, const float *__restrict__ VMap, F3 nl,
+                                                 const float *P, const float *__restrict__ Eq, float epsilon, float alpha,
+                                                 int i, int j, int n, int m) {
+    size_t idx = (size_t)i * m + j;
+    uint8_t res = 0;
+    F3 q = xf_dir(P, nl);
+    if (!is_zero3(q)) {
+        F3 pl = ld3(VMap, idx);
+        F3 p = xf_point(P, pl);
+        float depth = pl.z;
+        const float thresh_depth = 0.003f;
+        int lb = max(0, i - 1), ub = min(n, i + 2), lr = max(0, j - 1), ur = min(m, j + 2);
+        for (int ki = lb; ki < ub && res == 0; ki++)
+            for (int kj = lr; kj < ur; kj++) {
+                size_t nb = (size_t)ki * m + kj;
+                uint8_t l = in[nb];
+                if (l > 0 && __builtin_fabsf(VMap[3 * nb + 2] - depth) < thresh_depth) {
+                    const float *E = Eq + 10 * ((int)l - 1);
+                    float ed = ((p.x * E[0] + p.y * E[1]) + p.z * E[2]) - E[9];
+                    float ea = (q.x * E[0] + q.y * E[1]) + q.z * E[2];
+                    if (__builtin_fabsf(ed) > epsilon || ea < alpha) continue;
+                    res = l;
+                    break;
+                }
+            }
+    }
+    return res;
+}

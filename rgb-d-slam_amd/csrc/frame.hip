@@ -1,0 +1,330 @@
+// frame.hip -- the fused frame pipeline: each kernel here does the work of one METHOD of the
+// reference's L3 classes (OffLineFrame::LoadFrame, PredictedFrame::Transform+ReadFrame+ProjectMask+
+// ProjectLabel, PredictedFrame::Merge, PredictedFrame::Cpy+InitMask) instead of one kernel per
+// operator, with the per-pixel formulas of device_fns.hpp (bit-identical to the per-operator path).
+//
+// Why (tools/microbench/latency.hip, profiles/): at 640x480 every operator kernel moves 4-25 MB and
+// lasts 3-12 us -- the frame is bound by the NUMBER of dependent launches, not by bandwidth.  Fusing
+// removes ~20 launches per frame and the intermediate maps (texture, transformed VMap, index buffer)
+// never reach HBM.  Neighbourhood operators (normals, Sobel) read an LDS tile with a one-pixel halo.
+//
+// The tracker state lives in a device-resident rgbdslam_pose_block: the kernels read the poses that
+// the ICP loop produced from device memory and gate themselves on its `tracked` flag, so a frame is
+// a fixed launch sequence without any host round trip (the reference syncs after every operator and
+// reads the 27 sums back 12 times per frame).
+#include "device_fns.hpp"
+
+#define HALO_W (TILE_W + 2)
+#define HALO_H (TILE_H + 2)
+#define HALO_N (HALO_W * HALO_H)
+
+__device__ __forceinline__ bool pb_tracked(const rgbdslam_pose_block *pb) { return pb->status[0] == 1; }
+
+// ---- OffLineFrame::LoadFrame (D1/Frame.cpp:43-77) + gpu_cpy + 2 x cv::gpu::Sobel (D1/RG.cpp:807-810) --
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_frame_preprocess(const uint16_t *__restrict__ depth, size_t dpitch, const uint8_t *__restrict__ bgr, size_t bpitch,
+                        float *__restrict__ VMap, float *__restrict__ NMap, float *__restrict__ RGB,
+                        float *__restrict__ gx, size_t gx_pitch, float *__restrict__ gy, size_t gy_pitch, CalibV c,
+                        int n, int m) {
+    __shared__ float sv[HALO_H][HALO_W][3];   // vertices of the tile + halo
+    __shared__ float si[HALO_H][HALO_W];      // intensities, halo by reflect-101
+    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
+        int r = e / HALO_W, cc = e % HALO_W;
+        int ii = i0 + r - 1, jj = j0 + cc - 1;
+        bool in_img = ii >= 0 && ii < n && jj >= 0 && jj < m;
+        F3 v; v.x = v.y = v.z = 0.0f;
+        if (in_img) v = vertex_from_depth(((const uint16_t *)((const char *)depth + (size_t)(n - ii - 1) * dpitch))[jj], ii, jj, c);
+        sv[r][cc][0] = v.x; sv[r][cc][1] = v.y; sv[r][cc][2] = v.z;
+        float inten = 0.0f;
+        if (ii <= n && jj <= m) {   // one past the edge is still needed (reflected)
+            int si_ = reflect101(ii, n), sj = reflect101(jj, m);
+            const uint8_t *px = bgr + (size_t)(n - si_ - 1) * bpitch + 3 * (size_t)sj;
+            // (float)((double)x / 255.0) == x / 255.0f: double rounding is innocuous for division (53 >= 2*24+2)
+            float fr = (float)px[2] / 255.0f, fg = (float)px[1] / 255.0f, fb = (float)px[0] / 255.0f;   // Kernel.cu:749-751
+            inten = ((fb + fg) + fr) / 3.0f;                                                           // Kernel.cu:678
+            if (in_img && r >= 1 && r <= TILE_H && cc >= 1 && cc <= TILE_W) {
+                size_t idx = (size_t)ii * m + jj;
+                st3(RGB, idx, fr, fg, fb);
+                st3(VMap, idx, v.x, v.y, v.z);
+            }
+        }
+        si[r][cc] = inten;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const int r = threadIdx.y + 1, cc = threadIdx.x + 1;
+    size_t idx = (size_t)i * m + j;
+    // normals (Frame.cpp:71, inverse = true)
+    F3 nr; nr.x = nr.y = nr.z = 0.0f;
+    F3 p; p.x = sv[r][cc][0]; p.y = sv[r][cc][1]; p.z = sv[r][cc][2];
+    if (!(i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f)) {
+        F3 dn, up, rt, lf;
+        dn.x = sv[r + 1][cc][0]; dn.y = sv[r + 1][cc][1]; dn.z = sv[r + 1][cc][2];
+        up.x = sv[r - 1][cc][0]; up.y = sv[r - 1][cc][1]; up.z = sv[r - 1][cc][2];
+        rt.x = sv[r][cc + 1][0]; rt.y = sv[r][cc + 1][1]; rt.z = sv[r][cc + 1][2];
+        lf.x = sv[r][cc - 1][0]; lf.y = sv[r][cc - 1][1]; lf.z = sv[r][cc - 1][2];
+        nr = normal_from_cross(p, dn, up, rt, lf, 1);
+    }
+    st3(NMap, idx, nr.x, nr.y, nr.z);
+    // 3x3 Sobel, separable, the accumulation order of k_intensity_sobel
+    float rowd[3], rows[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = si[r - 1 + k][cc - 1], b = si[r - 1 + k][cc], d = si[r - 1 + k][cc + 1];
+        float s = 0.0f;
+        s = s + a * -1.0f; s = s + b * 0.0f; s = s + d * 1.0f;
+        rowd[k] = s;
+        s = 0.0f;
+        s = s + a * 1.0f; s = s + b * 2.0f; s = s + d * 1.0f;
+        rows[k] = s;
+    }
+    float s = 0.0f;
+    s = s + rowd[0] * 1.0f; s = s + rowd[1] * 2.0f; s = s + rowd[2] * 1.0f;
+    *(float *)((char *)gx + (size_t)i * gx_pitch + 4 * (size_t)j) = s;
+    s = 0.0f;
+    s = s + rows[0] * -1.0f; s = s + rows[1] * 0.0f; s = s + rows[2] * 1.0f;
+    *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
+}
+
+// ---- PredictedFrame::Cpy + InitMask (D1/Frame.cpp:335-370): model := input frame --------------------
+// runs when forced (first frame) or when the tracker reported a loss (GP-demo.cpp:164-167,189-193)
+__global__ void k_model_reseed(const rgbdslam_pose_block *__restrict__ pb, int force, const float *__restrict__ fV,
+                               const float *__restrict__ fN, const float *__restrict__ fRGB,
+                               const uint16_t *__restrict__ depth, size_t dpitch, float *__restrict__ VMap,
+                               float *__restrict__ NMap, float *__restrict__ RGBD, uint8_t *__restrict__ Mask, CalibV c,
+                               int n, int m) {
+    if (!force && pb_tracked(pb)) return;
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    F3 v = ld3(fV, idx), nn = ld3(fN, idx), col = ld3(fRGB, idx);
+    st3(VMap, idx, v.x, v.y, v.z);
+    st3(NMap, idx, nn.x, nn.y, nn.z);
+    float4 o;
+    o.x = col.x; o.y = col.y; o.z = col.z;
+    o.w = zbuff_w(((const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * dpitch))[j], c);
+    *(float4 *)(RGBD + 4 * idx) = o;
+    Mask[idx] = (o.w == 0.0f) ? 10 : 11;                           // Kernel.cu:624-627
+}
+
+// ---- PredictedFrame::Transform + the GL draw (Frame.cpp:281-298, GP-demo.cpp:98-113) ------------------
+// one lane per quad: the four vertices are warped by P_rel in registers (TransformVertexMapKernel),
+// trimmed (QuadTrimFrameKernel, on the warped vertices like the reference) and z-buffered.
+__device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) { return is_zero3(v) ? v : xf_point(P, v); }
+
+__global__ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
+                               unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
+                               int n, int m) {
+    if (!pb_tracked(pb)) return;
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i > n - 2 || j > m - 2) return;
+    const float *P = pb->P_rel;
+    uint32_t q = (uint32_t)(i * (m - 1) + j), id[4];
+    quad_vertex_ids(q, nullptr, m, id);
+    F3 v0 = warp_vertex(P, ld3(VMap, id[0])), v1 = warp_vertex(P, ld3(VMap, id[1])), v2 = warp_vertex(P, ld3(VMap, id[2])),
+       v3 = warp_vertex(P, ld3(VMap, id[3]));
+    if (quad_trimmed(v0, v1, v2, v3, thresh)) return;
+    F3 t0[3] = {v0, v1, v2}, t1[3] = {v0, v2, v3};
+    ras_draw(zbuf, t0, 2 * q, c, znear, zfar, n, m);
+    ras_draw(zbuf, t1, 2 * q + 1, c, znear, zfar, n, m);
+}
+
+// ---- resolve + PredictedFrame::ReadFrame + ProjectMask + the gather of ProjectLabel -------------------
+// (Frame.cpp:229-245,372-393).  Reads model set "in", writes model set "out" (ping-pong): the texel
+// never reaches memory.  Also resets the z-buffer word.
+__global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap_in,
+                                  const float *__restrict__ RGBD_in, const uint8_t *__restrict__ Mask_in,
+                                  const uint8_t *__restrict__ Label_in, unsigned long long *__restrict__ zbuf,
+                                  float *__restrict__ VMap_out, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
+                                  uint8_t *__restrict__ Label_out, CalibV c, int n, int m) {
+    if (!pb_tracked(pb)) return;
+    int px = blockIdx.x * TILE_W + threadIdx.x, py = blockIdx.y * TILE_H + threadIdx.y;
+    if (py >= n || px >= m) return;
+    size_t p = (size_t)py * m + px;
+    unsigned long long key = zbuf[p];
+    float4 tex; tex.x = tex.y = tex.z = tex.w = 0.0f;
+    if (key != ZBUF_EMPTY) {
+        zbuf[p] = ZBUF_EMPTY;
+        const float *P = pb->P_rel;
+        uint32_t tri_id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), id[4], vid[3];
+        quad_vertex_ids(tri_id >> 1, nullptr, m, id);
+        if (tri_id & 1) { vid[0] = id[0]; vid[1] = id[2]; vid[2] = id[3]; } else { vid[0] = id[0]; vid[1] = id[1]; vid[2] = id[2]; }
+        F3 vtx[3];
+        float4 att[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            vtx[k] = warp_vertex(P, ld3(VMap_in, vid[k]));
+            att[k] = *(const float4 *)(RGBD_in + 4 * (size_t)vid[k]);
+            att[k].w = depth_attr(vtx[k].z);                       // Kernel.cu:368-371
+        }
+        tex = ras_shade(vtx, att, c, px, py);
+    }
+    F3 v; v.x = v.y = v.z = 0.0f;
+    float4 o; o.x = o.y = o.z = o.w = 0.0f;
+    if (tex.w != 0.0f) { v = vertex_from_texel(tex.w, py, px, c); o = tex; }   // Kernel.cu:321-341
+    st3(VMap_out, p, v.x, v.y, v.z);
+    *(float4 *)(RGBD_out + 4 * p) = o;
+    long src = project_source(pb->P_rel_inv, c, v, n, m);          // Kernel.cu:634-667, for Mask and Label
+    Mask_out[p] = (src < 0) ? (uint8_t)0 : Mask_in[src];
+    Label_out[p] = (src < 0) ? (uint8_t)0 : Label_in[src];
+}
+
+// ---- ComputeNormal of ReadFrame (Frame.cpp:242) + first SegmentKernel pass (RG.cu:252-320) ------------
+// Eq == nullptr (no planes yet): normals only, labels copied.
+__global__ void k_normal_segment(const rgbdslam_pose_block *__restrict__ pb, float *__restrict__ NMap,
+                                 const float *__restrict__ VMap, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                 const float *__restrict__ Eq, float epsilon, float alpha, int n, int m) {
+    if (!pb_tracked(pb)) return;
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    F3 nl = normal_global(VMap, i, j, n, m, 1);
+    st3(NMap, idx, nl.x, nl.y, nl.z);
+    uint8_t mine = in[idx];
+    if (mine == 0 && Eq) mine = segment_pixel(in, VMap, nl, pb->P_glob, Eq, epsilon, alpha, i, j, n, m);
+    out[idx] = mine;
+}
+__global__ void k_segment_pass_pb(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ NMap,
+                                  const float *__restrict__ VMap, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                  const float *__restrict__ Eq, float epsilon, float alpha, int n, int m) {
+    if (!pb_tracked(pb)) return;
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    size_t idx = (size_t)i * m + j;
+    uint8_t mine = in[idx];
+    if (mine == 0) mine = segment_pixel(in, VMap, ld3(NMap, idx), pb->P_glob, Eq, epsilon, alpha, i, j, n, m);
+    out[idx] = mine;
+}
+
+// ---- PredictedFrame::Merge (Frame.cpp:300-333): MergeDepthOff + VertexMapGL + ComputeNormal -----------
+// set "in" -> set "out"; the merged vertices of the tile + halo are staged in LDS for the normals.
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ RGBD_in,
+                   const uint8_t *__restrict__ Mask_in, const uint16_t *__restrict__ depth, size_t dpitch,
+                   const float *__restrict__ RGB, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
+                   float *__restrict__ VMap_out, float *__restrict__ NMap_out, CalibV c, int n, int m) {
+    if (!pb_tracked(pb)) return;
+    __shared__ float sv[HALO_H][HALO_W][3];
+    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
+        int r = e / HALO_W, cc = e % HALO_W;
+        int ii = i0 + r - 1, jj = j0 + cc - 1;
+        F3 v; v.x = v.y = v.z = 0.0f;
+        if (ii >= 0 && ii < n && jj >= 0 && jj < m) {
+            size_t idx = (size_t)ii * m + jj;
+            uint16_t d = ((const uint16_t *)((const char *)depth + (size_t)(n - ii - 1) * dpitch))[jj];
+            uint8_t mk = Mask_in[idx];
+            int newmask;
+            bool own = r >= 1 && r <= TILE_H && cc >= 1 && cc <= TILE_W;
+            float w_old = own ? 0.0f : RGBD_in[4 * idx + 3];
+            float4 px;
+            if (own) { px = *(const float4 *)(RGBD_in + 4 * idx); w_old = px.w; }
+            float w = merge_pixel(w_old, d, mk, c, newmask);
+            v = vertex_from_w(w, ii, jj, c);
+            if (own) {
+                F3 col = ld3(RGB, idx);
+                px.x = col.x; px.y = col.y; px.z = col.z; px.w = w;
+                *(float4 *)(RGBD_out + 4 * idx) = px;
+                Mask_out[idx] = (newmask >= 0) ? (uint8_t)newmask : mk;
+                st3(VMap_out, idx, v.x, v.y, v.z);
+            }
+        }
+        sv[r][cc][0] = v.x; sv[r][cc][1] = v.y; sv[r][cc][2] = v.z;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const int r = threadIdx.y + 1, cc = threadIdx.x + 1;
+    F3 nr; nr.x = nr.y = nr.z = 0.0f;
+    F3 p; p.x = sv[r][cc][0]; p.y = sv[r][cc][1]; p.z = sv[r][cc][2];
+    if (!(i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f)) {
+        F3 dn, up, rt, lf;
+        dn.x = sv[r + 1][cc][0]; dn.y = sv[r + 1][cc][1]; dn.z = sv[r + 1][cc][2];
+        up.x = sv[r - 1][cc][0]; up.y = sv[r - 1][cc][1]; up.z = sv[r - 1][cc][2];
+        rt.x = sv[r][cc + 1][0]; rt.y = sv[r][cc + 1][1]; rt.z = sv[r][cc + 1][2];
+        lf.x = sv[r][cc - 1][0]; lf.y = sv[r][cc - 1][1]; lf.z = sv[r][cc - 1][2];
+        nr = normal_from_cross(p, dn, up, rt, lf, 1);
+    }
+    st3(NMap_out, (size_t)i * m + j, nr.x, nr.y, nr.z);
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int rgbdslam_frame_preprocess(rgbdslam_ctx *ctx, const uint16_t *depth, size_t depth_pitch, const uint8_t *bgr,
+                                         size_t bgr_pitch, float *VMap, float *NMap, float *RGB, float *gx, size_t gx_pitch,
+                                         float *gy, size_t gy_pitch, int n, int m) {
+    if (!ctx || !depth || !bgr || !VMap || !NMap || !RGB || !gx || !gy || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    if (depth_pitch < 2 * (size_t)m || bgr_pitch < 3 * (size_t)m || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m)
+        return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_frame_preprocess, grid2d(n, m), block2d(), depth, depth_pitch, bgr, bgr_pitch, VMap, NMap, RGB, gx, gx_pitch, gy,
+            gy_pitch, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_model_reseed(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, int force, const float *fVMap,
+                                     const float *fNMap, const float *fRGB, const uint16_t *depth, size_t depth_pitch,
+                                     float *VMap, float *NMap, float *RGBD, uint8_t *Mask, int n, int m) {
+    if (!ctx || (!pose_block_dev && !force) || !fVMap || !fNMap || !fRGB || !depth || !VMap || !NMap || !RGBD || !Mask)
+        return RGBDSLAM_E_ARG;
+    if (n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_model_reseed, grid2d(n, m), block2d(), pose_block_dev, force, fVMap, fNMap, fRGB, depth, depth_pitch, VMap, NMap,
+            RGBD, Mask, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
+                                      const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
+                                      float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
+                                      float znear, float zfar, int n, int m) {
+    if (!ctx || !pose_block_dev || !VMap_in || !RGBD_in || !Mask_in || !Label_in || !zbuf || !VMap_out || !RGBD_out ||
+        !Mask_out || !Label_out)
+        return RGBDSLAM_E_ARG;
+    if (VMap_in == VMap_out || RGBD_in == RGBD_out || Mask_in == Mask_out || Label_in == Label_out || n < 2 || m < 2)
+        return RGBDSLAM_E_ARG;
+    if ((size_t)n * m > 0x3FFFFFFFu) return RGBDSLAM_E_LIMIT;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_predict_draw, grid2d(n - 1, m - 1), block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
+            ctx->calib, znear, zfar, n, m);
+    KLAUNCH(ctx, k_predict_resolve, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
+            (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap,
+                                             const float *VMap, uint8_t *Label, uint8_t *Label_swap, const float *Equations_dev,
+                                             int nbPlans, float epsilon, float alpha, int n, int m) {
+    if (!ctx || !pose_block_dev || !NMap || !VMap || !Label || !Label_swap || Label == Label_swap || n <= 0 || m <= 0)
+        return RGBDSLAM_E_ARG;
+    if (nbPlans < 0 || nbPlans > 255 || (nbPlans > 0 && !Equations_dev)) return RGBDSLAM_E_LIMIT;
+    const float *Eq = nbPlans > 0 ? Equations_dev : nullptr;
+    KLAUNCH(ctx, k_normal_segment, grid2d(n, m), block2d(), pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m);
+    if (Eq) {                                                    // passes 2 and 3 (D1/RG.cu:910-911)
+        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), pose_block_dev, NMap, VMap, Label_swap, Label, Eq, epsilon, alpha, n, m);
+        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *RGBD_in,
+                                    const uint8_t *Mask_in, const uint16_t *depth, size_t depth_pitch, const float *RGB,
+                                    float *RGBD_out, uint8_t *Mask_out, float *VMap_out, float *NMap_out, int n, int m) {
+    if (!ctx || !pose_block_dev || !RGBD_in || !Mask_in || !depth || !RGB || !RGBD_out || !Mask_out || !VMap_out || !NMap_out)
+        return RGBDSLAM_E_ARG;
+    if (RGBD_in == RGBD_out || Mask_in == Mask_out || n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out,
+            VMap_out, NMap_out, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

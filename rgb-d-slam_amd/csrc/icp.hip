@@ -9,7 +9,8 @@
 // (D1/ICP.cu:50-70): the 27 sums are bit-identical to a serial restatement of the reference.
 #include "common.hpp"
 
-#define ICP_MAX_WAVES 8   // waves (= 8x8 blocks in flight) per workgroup
+#define ICP_MAX_WAVES 10  // waves (= 8x8 blocks in flight) per workgroup: 640x480 has 9.4 blocks per chain -> one balanced round
+#define ICP_TAIL_TERMS ((27 + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES)   // terms per wave in the tail
 #define ICP_TICKET_GROUP 16
 #define ICP_TICKET_WORDS (32 * (1 + 512 / ICP_TICKET_GROUP))
 #define ICP_CHAINS 512     // STRIDE (D1/cudaTypes.cuh:46): chains of ReduceKernel
@@ -194,7 +195,8 @@ struct IcpIterArgs {
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh);
 
-__global__ __launch_bounds__(64 * ICP_MAX_WAVES)
+// 6 waves per SIMD (<= 80 VGPRs): two 10-wave workgroups per CU, so all 512 chains are resident at once
+__global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void k_icp_iter(IcpIterArgs a) {
     __shared__ float part[ICP_MAX_WAVES][27];
     __shared__ float fin[27];
@@ -306,11 +308,11 @@ void k_icp_iter(IcpIterArgs a) {
 
     // second stage, tree part (reduce<512>, ICP.cu:28-48): offsets 256,128,64 combine the 8 values a
     // lane holds (t = lane + 64q), offsets 32..1 are lane shuffles.  Chains beyond nblk hold 0.
-    // Wave w owns terms w, w+8, w+16, w+24; all of its loads are issued before the first add so the
+    // Wave w owns terms w, w+W, w+2W...; all of its loads are issued before the first add so the
     // tail costs one memory round trip, not one per term.
-    float x[4][8];
+    float x[ICP_TAIL_TERMS][8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < ICP_TAIL_TERMS; u++) {
         int term = wave + ICP_MAX_WAVES * u;
 #pragma unroll
         for (int qd = 0; qd < 8; qd++) {
@@ -321,7 +323,7 @@ void k_icp_iter(IcpIterArgs a) {
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < ICP_TAIL_TERMS; u++) {
         int term = wave + ICP_MAX_WAVES * u;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) x[u][qd] = x[u][qd] + x[u][qd + 4];
@@ -643,7 +645,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.br_lo = br_lo; a.rows_local = br_hi - br_lo;
     long nblk = (long)a.rows_local * gc;
     a.nchain = (int)(nblk < ICP_CHAINS ? nblk : ICP_CHAINS);
-    a.nwaves = ICP_MAX_WAVES;   // always 8 waves: the last workgroup needs them for the 27-term tail
+    a.nwaves = ICP_MAX_WAVES;   // always full workgroups: the last one needs the waves for the 27-term tail
     a.chains = ctx->buf_dev; a.ticket = ctx->ticket_dev; a.sums = sums; a.corr = corr;
     a.state = state; a.pose_state = pose_state; a.do_solve = do_solve; a.lvl = lvl; a.iter = iter; a.max_iter = max_iter;
     a.thr_alpha = thr_alpha; a.thr_tr = thr_tr; a.trace = trace;

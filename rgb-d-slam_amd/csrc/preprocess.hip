@@ -1,7 +1,7 @@
 // preprocess.hip -- stage 1 (depth/colour -> vertex, normal, intensity-gradient maps) and the
 // per-pixel model maintenance kernels of stage 4/5 (merge, vertex-from-depth, model seeding).
 // Lanes run along image columns so every row segment is one coalesced burst.
-#include "common.hpp"
+#include "device_fns.hpp"
 
 // ---- D1/Kernel.cu:33-52 VertexMapKinectKernel ------------------------------------------------
 __global__ void k_vertex_map_kinect(float *__restrict__ VMap, const uint16_t *__restrict__ depth,
@@ -10,12 +10,8 @@ __global__ void k_vertex_map_kinect(float *__restrict__ VMap, const uint16_t *__
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
     const uint16_t *row = (const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * pitch);
-    uint16_t d = row[j];
-    if (d == 0) { st3(VMap, idx, 0.0f, 0.0f, 0.0f); return; }
-    float s = c.v[9] / c.v[10];
-    float fd = (float)d;
-    float sd = s * fd;
-    st3(VMap, idx, sd * (((float)j - c.v[2]) / c.v[0]), sd * (((float)i - c.v[3]) / c.v[1]), (-s) * fd);
+    F3 v = vertex_from_depth(row[j], i, j, c);
+    st3(VMap, idx, v.x, v.y, v.z);
 }
 
 // ---- D1/Kernel.cu:739-753 CpyKernelChar3 ------------------------------------------------------
@@ -28,65 +24,15 @@ __global__ void k_cpy_char3(const uint8_t *__restrict__ bgr, size_t pitch, float
         (float)((double)(float)px[0] / 255.0));
 }
 
-// ---- D1/Kernel.cu:123-307 NormalKernel --------------------------------------------------------
-// one of the four triangles around the pixel: normalised cross((a-p),(b-p)); returns 1 if counted
-__device__ __forceinline__ int tri_normal(F3 p, F3 a, F3 b, F3 &o) {
-    o.x = o.y = o.z = 0.0f;
-    if (a.z != 0.0f && b.z != 0.0f) {
-        float ax = a.x - p.x, ay = a.y - p.y, az = a.z - p.z;
-        float bx = b.x - p.x, by = b.y - p.y, bz = b.z - p.z;
-        float cx = ay * bz - az * by;
-        float cy = az * bx - ax * bz;
-        float cz = ax * by - ay * bx;
-        float nn = (cx * cx + cy * cy + cz * cz);
-        o.x = cx; o.y = cy; o.z = cz;
-        if (nn != 0.0f) {
-            float r = __builtin_sqrtf(nn);
-            o.x = cx / r; o.y = cy / r; o.z = cz / r;
-            return 1;
-        }
-    }
-    return 0;
-}
-
-__device__ __forceinline__ void normal_at(float *__restrict__ NMap, const float *__restrict__ VMap,
-                                          int i, int j, int n, int m, int inverse) {
-    size_t idx = (size_t)i * m + j;
-    F3 p = ld3(VMap, idx);
-    if (i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f) { st3(NMap, idx, 0.0f, 0.0f, 0.0f); return; }
-    F3 dn = ld3(VMap, idx + m), up = ld3(VMap, idx - m), rt = ld3(VMap, idx + 1), lf = ld3(VMap, idx - 1);
-    F3 n1, n2, n3, n4;
-    int tot = tri_normal(p, dn, rt, n1);
-    tot += tri_normal(p, rt, up, n2);
-    tot += tri_normal(p, up, lf, n3);
-    tot += tri_normal(p, lf, dn, n4);
-    if (tot == 0) { st3(NMap, idx, 0.0f, 0.0f, 0.0f); return; }
-    float ft = (float)tot;
-    float a0 = (((n1.x + n2.x) + n3.x) + n4.x) / ft;
-    float a1 = (((n1.y + n2.y) + n3.y) + n4.y) / ft;
-    float a2 = (((n1.z + n2.z) + n3.z) + n4.z) / ft;
-    float nn = __builtin_sqrtf((a0 * a0 + a1 * a1) + a2 * a2);
-    if (nn != 0.0f) {
-        if (inverse) st3(NMap, idx, (-a0) / nn, (-a1) / nn, (-a2) / nn);
-        else st3(NMap, idx, a0 / nn, a1 / nn, a2 / nn);
-    } else {
-        st3(NMap, idx, 0.0f, 0.0f, 0.0f);
-    }
-}
-
+// ---- D1/Kernel.cu:123-307 NormalKernel (device_fns.hpp) --------------------------------------------
 __global__ void k_compute_normal(float *__restrict__ NMap, const float *__restrict__ VMap, int n, int m, int inverse) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
-    normal_at(NMap, VMap, i, j, n, m, inverse);
+    F3 r = normal_global(VMap, i, j, n, m, inverse);
+    st3(NMap, (size_t)i * m + j, r.x, r.y, r.z);
 }
 
 // ---- D1/Kernel.cu:670-682 CpyKernel + cv::gpu::Sobel x2 (D1/RG.cpp:807-810), fused -------------
-__device__ __forceinline__ int reflect101(int p, int len) {
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
-    return p;
-}
-
 __global__ void k_intensity_sobel(const float *__restrict__ rgb, float *__restrict__ img, size_t img_pitch,
                                   float *__restrict__ gx, size_t gx_pitch, float *__restrict__ gy,
                                   size_t gy_pitch, int n, int m) {
@@ -136,49 +82,22 @@ __global__ void k_merge_depth_off(float *__restrict__ RGBD, const uint16_t *__re
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
     const uint16_t *row = (const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * pitch);
-    float ds = c.v[9], factor = c.v[10];
-    float dv = (ds / factor) * (float)row[j];
     float4 px = *(float4 *)(RGBD + 4 * idx);
-    float dp = (float)((double)px.w * SLAM_MAX_DEPTH);
-    float mv = (float)((double)(float)mask[idx] - 10.0);
-    const float mt = 1.0f;
     F3 col = ld3(RGB, idx);
+    int newmask;
+    px.w = merge_pixel(px.w, row[j], mask[idx], c, newmask);
     px.x = col.x; px.y = col.y; px.z = col.z;
-    int newmask = -1;
-    if ((double)dv < 0.1) {
-    } else if ((double)dp < 0.1 || __builtin_fabs((double)mv + 9.0) < 0.01) {
-        px.w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
-    } else if ((double)dv < ((double)dp - SLAM_MAXTOLERANCE)) {
-        px.w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
-    } else {
-        double mx = 1.0 > 1.0 * (double)dv ? 1.0 : 1.0 * (double)dv;
-        if ((double)dv > ((double)dp + mx * SLAM_MAXTOLERANCE)) {
-            newmask = 10;
-        } else {
-            float am = __builtin_fabsf(mv);
-            float avg = (dv * mt + am * dp) / (mt + am);
-            px.w = (float)((double)avg / SLAM_MAX_DEPTH);
-            double mk = (double)(mt + am) + 10.0;
-            if (mk > 255.0) mk = 255.0;
-            newmask = (int)(uint8_t)mk;
-        }
-    }
     *(float4 *)(RGBD + 4 * idx) = px;
     if (newmask >= 0) mask[idx] = (uint8_t)newmask;
 }
 
 // ---- D1/Kernel.cu:54-72 VertexMapGLKernel -------------------------------------------------------
-__device__ __forceinline__ void vertex_from_w(float *__restrict__ VMap, size_t idx, float w, int i, int j, const CalibV &c) {
-    double z = (double)w * SLAM_MAX_DEPTH;
-    float x = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)j - c.v[2]) / c.v[0]));
-    float y = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)i - c.v[3]) / c.v[1]));
-    st3(VMap, idx, x, y, (float)((double)(-w) * SLAM_MAX_DEPTH));
-}
 __global__ void k_vertex_map_gl(float *__restrict__ VMap, const float *__restrict__ RGBD, CalibV c, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
-    vertex_from_w(VMap, idx, RGBD[4 * idx + 3], i, j, c);
+    F3 v = vertex_from_w(RGBD[4 * idx + 3], i, j, c);
+    st3(VMap, idx, v.x, v.y, v.z);
 }
 
 // ---- D1/Kernel.cu:783-802 AddZBUFFOffKernel, 616-632 InitMaskKernel -----------------------------
@@ -188,11 +107,10 @@ __global__ void k_add_zbuff_off(const uint16_t *__restrict__ depth, size_t pitch
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
     const uint16_t *row = (const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * pitch);
-    float z = (c.v[9] / c.v[10]) * (float)row[j];
     F3 col = ld3(rgb_in, idx);
     float4 o;
     o.x = col.x; o.y = col.y; o.z = col.z;
-    o.w = ((double)z > SLAM_MAX_DEPTH || (double)z < 0.0) ? 0.0f : (float)((double)z / SLAM_MAX_DEPTH);
+    o.w = zbuff_w(row[j], c);
     *(float4 *)(RGBD + 4 * idx) = o;
 }
 __global__ void k_init_mask(uint8_t *__restrict__ mask, const float *__restrict__ RGBD, int n, int m) {
