@@ -137,6 +137,65 @@ int rgbdslam_align_solve_gathered(rgbdslam_ctx *ctx, const rgbdslam_icp_params *
                                   int lvl, int iter, float *trace_dev);
 int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int32_t *status_dev);
 
+/* ---- fused frame pipeline ------------------------------------------------------------------
+ * One entry point per METHOD of the reference's L3/L4 classes instead of one per operator; same
+ * per-pixel arithmetic (results are bit-identical to the per-operator entry points).  The tracker
+ * state is a device-resident rgbdslam_pose_block: rgbdslam_track_frame writes it, the model_*
+ * entry points read their poses from it and do nothing when `tracked` is 0 (model_reseed: nothing
+ * when it is 1), so a whole display() pass (GP-demo.cpp:138-296) is a fixed, sync-free launch
+ * sequence.  The model is double-buffered (set "in" -> set "out"). */
+typedef struct rgbdslam_pose_block {
+    float pose_state[24];  /* poseR(9, col-major) poset(3) poseRPrev(9) posetPrev(3)  RG.h:55-58 */
+    int32_t status[4];     /* [0] 1 tracked / 0 lost, [1] iterations, [2] per level (8 bits each), [3] frames tracked so far */
+    float P_rel[16];       /* model -> current camera, col-major 4x4 (pose_inv of GP-demo.cpp:201-211) */
+    float P_rel_inv[16];   /* GP-demo.cpp:225-236 */
+    float P_glob[16];      /* current camera -> world (pose of GP-demo.cpp:230-235,254-259) */
+} rgbdslam_pose_block;
+/* OffLineFrame::LoadFrame (Frame.cpp:43-77: gpu_cpy_char3 + VertexMapKinect + ComputeNormal) plus
+ * gpu_cpy and the two cv::gpu::Sobel calls of RG.cpp:807-810, one kernel. */
+int rgbdslam_frame_preprocess(rgbdslam_ctx *ctx, const uint16_t *depth, size_t depth_pitch_bytes,
+                              const uint8_t *bgr, size_t bgr_pitch_bytes, float *VMap, float *NMap,
+                              float *RGB, float *gx, size_t gx_pitch, float *gy, size_t gy_pitch,
+                              int n, int m);
+/* RG::AlignFrameGaussNewton (RG.cpp:797-932) followed by the pose algebra of display()
+ * (GP-demo.cpp:201-211,225-236,244-245,192-193): fills pose_block_dev on the device.
+ * history_dev (optional): f32[16] per frame -- poseR(9) poset(3) tracked iterations level_iters 0 --
+ * written at slot frame_index. */
+int rgbdslam_track_frame(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap,
+                         const float *NMap, const float *RGB, const float *Gx, size_t gx_pitch,
+                         const float *Gy, size_t gy_pitch, const float *VMap_prev,
+                         const float *NMap_prev, const float *RGB_prev, int n_row, int m_col,
+                         rgbdslam_pose_block *pose_block_dev, float *history_dev, int frame_index);
+/* PredictedFrame::Cpy + InitMask (Frame.cpp:335-370).  Runs if force != 0 or the block says lost. */
+int rgbdslam_model_reseed(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, int force,
+                          const float *frame_VMap, const float *frame_NMap, const float *frame_RGB,
+                          const uint16_t *depth, size_t depth_pitch_bytes, float *VMap, float *NMap,
+                          float *RGBD, uint8_t *Mask, int n, int m);
+/* PredictedFrame::Transform + DisplayPredictedFBO + ReadFrame (without its normals) + ProjectMask +
+ * the gather half of ProjectLabel (Frame.cpp:281-298,229-245,372-393; GP-demo.cpp:98-113). */
+int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                           const float *VMap_in, const float *RGBD_in, const uint8_t *Mask_in,
+                           const uint8_t *Label_in, uint64_t *zbuf, float *VMap_out, float *RGBD_out,
+                           uint8_t *Mask_out, uint8_t *Label_out, float thresh, float znear,
+                           float zfar, int n, int m);
+/* ComputeNormal of ReadFrame (Frame.cpp:242) + Segment_cu (Frame.cpp:395).  The result is left in
+ * Label_swap (one pass when nbPlans == 0, three otherwise: always an odd number of swaps). */
+int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                                  float *NMap, const float *VMap, uint8_t *Label, uint8_t *Label_swap,
+                                  const float *Equations_dev, int nbPlans, float epsilon,
+                                  float alpha, int n, int m);
+/* PredictedFrame::Merge (Frame.cpp:300-333): MergeDepthOff + VertexMapGL + ComputeNormal. */
+int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                         const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
+                         size_t depth_pitch_bytes, const float *RGB, float *RGBD_out,
+                         uint8_t *Mask_out, float *VMap_out, float *NMap_out, int n, int m);
+/* Graph::Update (Graph.cpp:50-95) with the pose taken from the block (P_glob) and gated on it. */
+int rgbdslam_update_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                            uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                            uint64_t **ClaimTab, uint32_t stamp, const float *VMap, const float *RGBD,
+                            const uint8_t *Mask, const uint8_t *Label, int N_prim, int M_prim, int n,
+                            int m, int plane_lo, int plane_hi);
+
 /* ---- stage 4: fusion ---------------------------------------------------------------------- */
 /* Kernel.cuh:21  void MergeDepthOff(float *RGB_predicted, DevMem2D_<unsigned short> depth,
  *                                   float *RGB, unsigned char *mask, int n, int m) */

@@ -236,6 +236,17 @@ class RG:
         except Exception:
             pass
 
+    def set_fused(self, on):
+        """True (default): fused, sync-free frame pipeline; False: one C-ABI call per reference operator."""
+        _hchk(self.lib.slamhost_rg_set_fused(self._h, int(on)), "set_fused")
+
+    def history(self, first, count):
+        """Poses of frames [first, first+count): rows of poseR(9, col-major) poset(3) tracked iterations level_iters 0."""
+        import numpy as np
+        out = np.empty((count, 16), np.float32)
+        _hchk(self.lib.slamhost_rg_history(self._h, int(first), int(count), C.c_void_p(out.ctypes.data)), "history")
+        return out
+
     def set_device_loop(self, on):
         _hchk(self.lib.slamhost_rg_set_device_loop(self._h, int(on)), "set_device_loop")
 

@@ -573,19 +573,61 @@ void k_icp_solve(IcpState *st, const float *__restrict__ gathered, int parts, co
     icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh);
 }
 
-__global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status) {
+__device__ __forceinline__ void d_pack_pose(const float *R, const float *t, float *P) {   // GP-demo.cpp:206-211
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) P[j * 4 + i] = M3(R, i, j);
+    for (int i = 0; i < 3; i++) P[12 + i] = t[i];
+    P[3] = 0.0f; P[7] = 0.0f; P[11] = 0.0f; P[15] = 1.0f;
+}
+
+// pb (optional): pose_state/status are the block's own fields; the display() pose algebra is
+// appended (GP-demo.cpp:201-211,225-236) and the previous pose advanced (244-245 / 192-193).
+__global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status, rgbdslam_pose_block *pb, float *history,
+                          int frame_index) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     status[1] = st->iters;
     status[2] = st->lvl_iters;
-    if (st->fail) { status[0] = 0; return; }
-    if ((double)d_frob_minus_I(st->Rcurr) > 0.3 || (double)d_norm3(st->tcurr) > 0.3) { status[0] = 0; return; }  // RG.cpp:910
-    float R[9], neg[9], t[3];
-    d_inverse3(st->Rinv, R);                                   // RG.cpp:923
-    for (int k = 0; k < 9; k++) neg[k] = -R[k];
-    d_mat3_vec(neg, st->tinv, t);                              // RG.cpp:924
-    for (int k = 0; k < 9; k++) pose_state[k] = R[k];
-    for (int k = 0; k < 3; k++) pose_state[9 + k] = t[k];
-    status[0] = 1;
+    int ok = !st->fail;
+    if (ok && ((double)d_frob_minus_I(st->Rcurr) > 0.3 || (double)d_norm3(st->tcurr) > 0.3)) ok = 0;   // RG.cpp:910
+    if (ok) {
+        float R[9], neg[9], t[3];
+        d_inverse3(st->Rinv, R);                               // RG.cpp:923
+        for (int k = 0; k < 9; k++) neg[k] = -R[k];
+        d_mat3_vec(neg, st->tinv, t);                          // RG.cpp:924
+        for (int k = 0; k < 9; k++) pose_state[k] = R[k];
+        for (int k = 0; k < 3; k++) pose_state[9 + k] = t[k];
+    }
+    status[0] = ok;
+    if (pb) {
+        float R[9], t[3], Rp[9], tp[3];
+        for (int k = 0; k < 9; k++) { R[k] = pose_state[k]; Rp[k] = pose_state[12 + k]; }
+        for (int k = 0; k < 3; k++) { t[k] = pose_state[9 + k]; tp[k] = pose_state[21 + k]; }
+        if (ok) {
+            float Rinv[9], neg[9], tinv[3], Rrel[9], trel[3], tmp[3];
+            d_inverse3(R, Rinv);                               // GP-demo.cpp:201-205
+            for (int k = 0; k < 9; k++) neg[k] = -Rinv[k];
+            d_mat3_vec(neg, t, tinv);
+            d_mat3_mul(Rinv, Rp, Rrel);
+            d_mat3_vec(Rinv, tp, tmp);
+            trel[0] = tmp[0] + tinv[0]; trel[1] = tmp[1] + tinv[1]; trel[2] = tmp[2] + tinv[2];
+            d_pack_pose(Rrel, trel, pb->P_rel);
+            float RrelInv[9], trelInv[3];
+            d_inverse3(Rrel, RrelInv);                         // GP-demo.cpp:225-236
+            for (int k = 0; k < 9; k++) neg[k] = -RrelInv[k];
+            d_mat3_vec(neg, trel, trelInv);
+            d_pack_pose(RrelInv, trelInv, pb->P_rel_inv);
+            d_pack_pose(R, t, pb->P_glob);
+            status[3] = status[3] + 1;
+        }
+        for (int k = 0; k < 9; k++) pose_state[12 + k] = R[k]; // _poseRPrev = _poseR (both branches)
+        for (int k = 0; k < 3; k++) pose_state[21 + k] = t[k];
+        if (history) {
+            float *h = history + 16 * (size_t)frame_index;
+            for (int k = 0; k < 9; k++) h[k] = R[k];
+            for (int k = 0; k < 3; k++) h[9 + k] = t[k];
+            h[12] = (float)ok; h[13] = (float)st->iters; h[14] = (float)st->lvl_iters; h[15] = 0.0f;
+        }
+    }
 }
 
 // =================================================================================================
@@ -689,11 +731,11 @@ static int check_align_args(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, i
     return 0;
 }
 
-extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap,
-                                           const float *NMap, const float *RGB, const float *Gx, size_t gxp,
-                                           const float *Gy, size_t gyp, const float *VMap_prev, const float *NMap_prev,
-                                           const float *RGB_prev, int n, int m, float *pose_state_dev,
-                                           int32_t *status_dev, float *trace_dev) {
+static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap, const float *NMap,
+                      const float *RGB, const float *Gx, size_t gxp, const float *Gy, size_t gyp, const float *VMap_prev,
+                      const float *NMap_prev, const float *RGB_prev, int n, int m, float *pose_state_dev,
+                      int32_t *status_dev, float *trace_dev, rgbdslam_pose_block *pose_block, float *history,
+                      int frame_index) {
     if (!ctx || !prm || !VMap || !NMap || !RGB || !Gx || !Gy || !VMap_prev || !NMap_prev || !RGB_prev ||
         !pose_state_dev || !status_dev)
         return RGBDSLAM_E_ARG;
@@ -713,9 +755,27 @@ extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp
         }
         fact /= 2;
     }
-    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev);
+    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev, pose_block, history, frame_index);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap,
+                                           const float *NMap, const float *RGB, const float *Gx, size_t gxp,
+                                           const float *Gy, size_t gyp, const float *VMap_prev, const float *NMap_prev,
+                                           const float *RGB_prev, int n, int m, float *pose_state_dev,
+                                           int32_t *status_dev, float *trace_dev) {
+    return align_impl(ctx, prm, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev, NMap_prev, RGB_prev, n, m, pose_state_dev, status_dev,
+                      trace_dev, nullptr, nullptr, 0);
+}
+
+extern "C" int rgbdslam_track_frame(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap, const float *NMap,
+                                    const float *RGB, const float *Gx, size_t gxp, const float *Gy, size_t gyp,
+                                    const float *VMap_prev, const float *NMap_prev, const float *RGB_prev, int n, int m,
+                                    rgbdslam_pose_block *pb, float *history_dev, int frame_index) {
+    if (!pb || frame_index < 0) return RGBDSLAM_E_ARG;
+    return align_impl(ctx, prm, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev, NMap_prev, RGB_prev, n, m, pb->pose_state, pb->status,
+                      nullptr, pb, history_dev, frame_index);
 }
 
 // ---- row-sharded Gauss-Newton loop (BASELINE configs[3]): the caller interleaves a
@@ -758,7 +818,8 @@ extern "C" int rgbdslam_align_solve_gathered(rgbdslam_ctx *ctx, const rgbdslam_i
 extern "C" int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int32_t *status_dev) {
     if (!ctx || !pose_state_dev || !status_dev) return RGBDSLAM_E_ARG;
     if (!ctx->icp_state) return RGBDSLAM_E_STATE;
-    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), ctx->icp_state, pose_state_dev, status_dev);
+    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), ctx->icp_state, pose_state_dev, status_dev, (rgbdslam_pose_block *)nullptr,
+            (float *)nullptr, 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }

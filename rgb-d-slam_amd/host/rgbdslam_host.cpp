@@ -198,6 +198,11 @@ void OffLineFrame::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch
 }
 
 void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
+    if (_gx) {
+        check(rgbdslam_frame_preprocess(_ctx, _depth_cur, _depth_pitch, bgr, bgr_pitch, _VMap_dev.p, _NMap_dev.p, _RGB_dev.p, _gx,
+                                        _gpitch, _gy, _gpitch, _n, _m), "frame_preprocess");
+        return;
+    }
     check(rgbdslam_gpu_cpy_char3(_ctx, bgr, bgr_pitch, _RGB_dev.p, _n, _m), "gpu_cpy_char3");            // Frame.cpp:65
     check(rgbdslam_vertex_map_kinect(_ctx, _VMap_dev.p, _depth_cur, _depth_pitch, _n, _m), "VertexMapKinect");  // :68
     check(rgbdslam_compute_normal(_ctx, _NMap_dev.p, _VMap_dev.p, _n, _m, 1), "ComputeNormal");           // :71
@@ -210,6 +215,8 @@ PredictedFrame::PredictedFrame(rgbdslam_ctx *ctx, int n, int m) : _n(n), _m(m), 
     _NMap_dev.alloc(3 * P);
     _RGB_dev.alloc(4 * P);
     _tex.alloc(4 * P);
+    _VMap_alt.alloc(3 * P);
+    _RGB_alt.alloc(4 * P);
     _mask_a.alloc(P); _mask_b.alloc(P); _label_a.alloc(P); _label_b.alloc(P);
     _Mask_dev = _mask_a.p; _Mask_dev_swap = _mask_b.p;
     _Label_dev = _label_a.p; _Label_dev_swap = _label_b.p;
@@ -273,6 +280,25 @@ void PredictedFrame::ProjectLabel(float *pose_loc, float *pose_glob, float *Equa
                                0.1f, 0.9f, _n, _m), "Segment_cu");                                          // Frame.cpp:395
 }
 
+// ---- fused forms ------------------------------------------------------------------------------------
+void PredictedFrame::ReseedFused(const rgbdslam_pose_block *pb, int force, OffLineFrame *frame) {
+    check(rgbdslam_model_reseed(_ctx, pb, force, frame->getVMap(), frame->getNMap(), frame->getRGB(), frame->depth(),
+                                frame->depth_pitch(), _VMap_dev.p, _NMap_dev.p, _RGB_dev.p, _Mask_dev, _n, _m), "model_reseed");
+}
+void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar) {
+    check(rgbdslam_model_predict(_ctx, pb, _VMap_dev.p, _RGB_dev.p, _Mask_dev, _Label_dev, _zbuf.p, _VMap_alt.p, _RGB_alt.p,
+                                 _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m), "model_predict");
+}
+void PredictedFrame::NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans) {
+    // projected labels are in _Label_dev_swap; an odd number of passes brings them back to _Label_dev
+    check(rgbdslam_model_normal_segment(_ctx, pb, _NMap_dev.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans,
+                                        0.1f, 0.9f, _n, _m), "model_normal_segment");
+}
+void PredictedFrame::MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame) {
+    check(rgbdslam_model_merge(_ctx, pb, _RGB_alt.p, _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(),
+                               _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p, _n, _m), "model_merge");
+}
+
 // ---- Primitive (D1/Primitive.h:79-112,165-190) --------------------------------------------------------
 Primitive::Primitive(float *nmle, float *e1, float *e2, float dist, float *scale, int *Size, float *Shift, float *anchor) {
     for (int k = 0; k < 3; k++) { _nmle[k] = nmle[k]; _e1[k] = e1[k]; _e2[k] = e2[k]; _anchor[k] = anchor[k]; }
@@ -332,31 +358,41 @@ bool Graph::AddPrimitive(Primitive *Prim) {
     _tables_built = false;
     return true;
 }
-void Graph::Update(PredictedFrame *frame, float *pose) {
+void Graph::build_tables() {                                                       // Graph.cpp:56-70
     size_t S = _nodes.size();
-    if (S == 0) return;                                                            // Graph.cpp:53-54
-    if (!_tables_built) {                                                          // Graph.cpp:56-70
-        std::vector<void *> bt(S), rt(S), mt(S), pt(S), ct(S);
-        for (size_t i = 0; i < S; i++) {
-            Primitive *Prim = _nodes[i];
-            Prim->SetParam();
-            bt[i] = Prim->_Bump_dev; rt[i] = Prim->_RGB_dev; mt[i] = Prim->_Mask_dev; pt[i] = Prim->_param_dev.p;
-            ct[i] = Prim->_Claim_dev;
-        }
-        // one H2D copy per table replaces the 1-thread Affect* kernels (D1/RG.cu:557-567)
-        DevBuf<void *> *tabs[5] = {&_BumpTab, &_RGBTab, &_MaskTab, &_ParamTab, &_ClaimTab};
-        std::vector<void *> *src[5] = {&bt, &rt, &mt, &pt, &ct};
-        for (int k = 0; k < 5; k++) {
-            tabs[k]->alloc(S, false);
-            hip_check(hipMemcpy(tabs[k]->p, src[k]->data(), S * sizeof(void *), hipMemcpyHostToDevice), "pointer table");
-        }
-        _tables_built = true;
+    std::vector<void *> bt(S), rt(S), mt(S), pt(S), ct(S);
+    for (size_t i = 0; i < S; i++) {
+        Primitive *Prim = _nodes[i];
+        Prim->SetParam();
+        bt[i] = Prim->_Bump_dev; rt[i] = Prim->_RGB_dev; mt[i] = Prim->_Mask_dev; pt[i] = Prim->_param_dev.p;
+        ct[i] = Prim->_Claim_dev;
     }
+    // one H2D copy per table replaces the 1-thread Affect* kernels (D1/RG.cu:557-567)
+    DevBuf<void *> *tabs[5] = {&_BumpTab, &_RGBTab, &_MaskTab, &_ParamTab, &_ClaimTab};
+    std::vector<void *> *src[5] = {&bt, &rt, &mt, &pt, &ct};
+    for (int k = 0; k < 5; k++) {
+        tabs[k]->alloc(S, false);
+        hip_check(hipMemcpy(tabs[k]->p, src[k]->data(), S * sizeof(void *), hipMemcpyHostToDevice), "pointer table");
+    }
+    _tables_built = true;
+}
+void Graph::Update(PredictedFrame *frame, float *pose) {
+    if (_nodes.size() == 0) return;                                                // Graph.cpp:53-54
+    if (!_tables_built) build_tables();
     _stamp++;
     check(rgbdslam_update(_ctx, (uint16_t **)_BumpTab.p, (uint8_t **)_RGBTab.p, (uint8_t **)_MaskTab.p, (float **)_ParamTab.p,
                           (uint64_t **)_ClaimTab.p, _stamp, frame->getVMap(), frame->getRGB(), frame->_Mask_dev,
                           frame->_Label_dev, pose, _SizeVBUFF[0], _SizeVBUFF[1], frame->_n, frame->_m, plane_lo, plane_hi),
           "Update_cu");                                                            // Graph.cpp:74
+}
+void Graph::UpdateTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb) {
+    if (_nodes.size() == 0) return;
+    if (!_tables_built) build_tables();
+    _stamp++;
+    check(rgbdslam_update_tracked(_ctx, pb, (uint16_t **)_BumpTab.p, (uint8_t **)_RGBTab.p, (uint8_t **)_MaskTab.p,
+                                  (float **)_ParamTab.p, (uint64_t **)_ClaimTab.p, _stamp, frame->getVMap(), frame->getRGB(),
+                                  frame->_Mask_dev, frame->_Label_dev, _SizeVBUFF[0], _SizeVBUFF[1], frame->_n, frame->_m, plane_lo,
+                                  plane_hi), "Update_cu (tracked)");
 }
 
 // ---- RG (D1/RG.h:111-250, D1/RG.cpp) -------------------------------------------------------------------
@@ -381,6 +417,16 @@ RG::RG(int device, void *stream, int n, int m, const float *Calib, int lvl, floa
     _img1.alloc(P); _Gx.alloc(P); _Gy.alloc(P);
     _pose_state_dev.alloc(24); _status_dev.alloc(4); _trace_dev.alloc(33 * 16);
     hip_check(hipHostMalloc((void **)&_pinned, 32 * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+    // fused pipeline state: device pose block (identity poses), pinned mirror, pose history ring
+    hip_check(hipMalloc((void **)&_pb_dev, sizeof(rgbdslam_pose_block)), "hipMalloc pose block");
+    hip_check(hipHostMalloc((void **)&_pb_host, sizeof(rgbdslam_pose_block), hipHostMallocDefault), "hipHostMalloc");
+    memset(_pb_host, 0, sizeof(rgbdslam_pose_block));
+    memcpy(_pb_host->pose_state, _poseR.a, 36);
+    memcpy(_pb_host->pose_state + 12, _poseRPrev.a, 36);
+    hip_check(hipMemcpy(_pb_dev, _pb_host, sizeof(rgbdslam_pose_block), hipMemcpyHostToDevice), "pose block init");
+    _history_dev.alloc(16 * (size_t)HISTORY_CAP);
+    hip_check(hipHostMalloc((void **)&_history_host, 16 * (size_t)HISTORY_CAP * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+    _frame->AttachGradients(_Gx.p, _Gy.p, 4 * (size_t)m);
 }
 
 RG::~RG() {
@@ -389,6 +435,10 @@ RG::~RG() {
     delete _predicted_frame;
     delete _frame;
     if (_pinned) (void)hipHostFree(_pinned);
+    if (_pb_dev) (void)hipFree(_pb_dev);
+    if (_pb_host) (void)hipHostFree(_pb_host);
+    if (_history_host) (void)hipHostFree(_history_host);
+    _history_dev.release();
     _intr_dev.release(); _Rcurr_dev.release(); _tcurr_dev.release(); _img1.release(); _Gx.release(); _Gy.release();
     _pose_state_dev.release(); _status_dev.release(); _trace_dev.release(); _Equations_dev.release();
     if (_ctx) (void)rgbdslam_destroy(_ctx);
@@ -409,8 +459,8 @@ bool RG::AlignFrameGaussNewton() {
     int n = _frame->getN(), m = _frame->getM();
     size_t pitch = 4 * (size_t)m;
     hipStream_t s = ctx_stream(_ctx);
-    // gpu_cpy + 2 x cv::gpu::Sobel, fused (RG.cpp:807-810)
-    check(rgbdslam_intensity_sobel(_ctx, _frame->getRGB(), nullptr, 0, _Gx.p, pitch, _Gy.p, pitch, n, m), "intensity_sobel");
+    // gpu_cpy + 2 x cv::gpu::Sobel, fused (RG.cpp:807-810); already done by frame_preprocess when attached
+    if (!_frame->has_gradients()) check(rgbdslam_intensity_sobel(_ctx, _frame->getRGB(), nullptr, 0, _Gx.p, pitch, _Gy.p, pitch, n, m), "intensity_sobel");
     float *VMap_prev = _predicted_frame->getVMap(), *NMap_prev = _predicted_frame->getNMap();
     float *VMap = _frame->getVMap(), *NMap = _frame->getNMap();
 
@@ -419,11 +469,7 @@ bool RG::AlignFrameGaussNewton() {
         float *ps = _pinned;
         memcpy(ps, _poseR.a, 36); memcpy(ps + 9, _poset.v, 12); memcpy(ps + 12, _poseRPrev.a, 36); memcpy(ps + 21, _posetPrev.v, 12);
         hip_check(hipMemcpyAsync(_pose_state_dev.p, ps, 96, hipMemcpyHostToDevice, s), "pose upload");
-        rgbdslam_icp_params prm;
-        prm.lvl = _lvl;
-        for (int k = 0; k < 3; k++) prm.max_iter[k] = _max_iter[k];
-        prm.distThres = _distThres; prm.angleThres = _angleThres;
-        prm.thres_cvg_alpha = _thres_cvg_alpha; prm.thres_cvg_tr = _thres_cvg_tr;
+        rgbdslam_icp_params prm = icp_params();
         check(rgbdslam_align_gauss_newton(_ctx, &prm, VMap, NMap, _frame->getRGB(), _Gx.p, pitch, _Gy.p, pitch, VMap_prev,
                                           NMap_prev, _predicted_frame->getRGB(), n, m, _pose_state_dev.p, _status_dev.p, nullptr),
               "align_gauss_newton");
@@ -533,7 +579,65 @@ void RG::CreatePrimitives(float *pose) {
                                _Equations_dev.p, _nbPlan, 0.1f, 0.8f, _predicted_frame->_n, _predicted_frame->_m), "seed_labels");
 }
 
+rgbdslam_icp_params RG::icp_params() const {
+    rgbdslam_icp_params prm;
+    prm.lvl = _lvl;
+    for (int k = 0; k < 3; k++) prm.max_iter[k] = _max_iter[k];
+    prm.distThres = _distThres; prm.angleThres = _angleThres;
+    prm.thres_cvg_alpha = _thres_cvg_alpha; prm.thres_cvg_tr = _thres_cvg_tr;
+    return prm;
+}
+
+// display() (GP-demo.cpp:138-296) as a fixed launch sequence: no host decision depends on device
+// results, so nothing here waits for the GPU.
+int RG::StepAsync() {
+    int n = _frame->getN(), m = _frame->getM();
+    size_t pitch = 4 * (size_t)m;
+    bool first = (_count == 2);
+    if (first) _predicted_frame->ReseedFused(nullptr, 1, _frame);                   // GP-demo.cpp:164-167
+    rgbdslam_icp_params prm = icp_params();
+    check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _Gx.p, pitch, _Gy.p, pitch,
+                               _predicted_frame->getVMap(), _predicted_frame->getNMap(), _predicted_frame->getRGB(), n, m, _pb_dev,
+                               _history_dev.p, frames_done % HISTORY_CAP), "track_frame");   // GP-demo.cpp:189 + 201-245
+    _predicted_frame->ReseedFused(_pb_dev, 0, _frame);                              // GP-demo.cpp:190-191 (only if lost)
+    _predicted_frame->PredictFused(_pb_dev, Znear, Zfar);                           // GP-demo.cpp:215-237 + ProjectLabel gather
+    _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);       // Frame.cpp:242 + 395
+    _predicted_frame->MergeFused(_pb_dev, _frame);                                  // GP-demo.cpp:249
+    _graph->UpdateTracked(_predicted_frame, _pb_dev);                               // GP-demo.cpp:260
+    frames_done++;
+    return first ? 2 : 1;
+}
+
+int RG::Sync() {
+    hipStream_t s = ctx_stream(_ctx);
+    hip_check(hipMemcpyAsync(_pb_host, _pb_dev, sizeof(rgbdslam_pose_block), hipMemcpyDeviceToHost, s), "pose block download");
+    int lo = _history_synced, hi = frames_done;
+    if (hi - lo > HISTORY_CAP) lo = hi - HISTORY_CAP;
+    for (int f = lo; f < hi;) {                                                     // ring segments
+        int slot = f % HISTORY_CAP, cnt = hi - f;
+        if (slot + cnt > HISTORY_CAP) cnt = HISTORY_CAP - slot;
+        hip_check(hipMemcpyAsync(_history_host + 16 * (size_t)slot, _history_dev.p + 16 * (size_t)slot, 64 * (size_t)cnt,
+                                 hipMemcpyDeviceToHost, s), "history download");
+        f += cnt;
+    }
+    hip_check(hipStreamSynchronize(s), "sync");
+    _history_synced = hi;
+    memcpy(_poseR.a, _pb_host->pose_state, 36); memcpy(_poset.v, _pb_host->pose_state + 9, 12);
+    memcpy(_poseRPrev.a, _pb_host->pose_state + 12, 36); memcpy(_posetPrev.v, _pb_host->pose_state + 21, 12);
+    last_iterations = _pb_host->status[1];
+    last_level_iterations = _pb_host->status[2];
+    tracked_total = _pb_host->status[3];
+    return _pb_host->status[0];
+}
+
+const float *RG::history_host(int frame_index) { return _history_host + 16 * (size_t)(frame_index % HISTORY_CAP); }
+
 int RG::Step() {
+    if (fused) {
+        int r = StepAsync();
+        int ok = Sync();
+        return ok ? r : 0;
+    }
     float pose[16], pose_inv[16];
     bool first = false;
     if (_count == 2) {                                                              // GP-demo.cpp:164-167
@@ -596,14 +700,34 @@ int slamhost_rg_destroy(void *rg) {
     delete (RG *)rg;
     return 0;
 }
+int slamhost_rg_set_fused(void *rg, int on);
 int slamhost_rg_set_device_loop(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     ((RG *)rg)->device_loop = on != 0;
+    if (!on) return slamhost_rg_set_fused(rg, 0);              // the per-iteration host solve is the unfused path
+    return 0;
+}
+int slamhost_rg_set_fused(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    if (r->_count != 1) return RGBDSLAM_E_STATE;               // choose before the first frame
+    r->fused = on != 0;
+    if (!r->fused) r->_frame->AttachGradients(nullptr, nullptr, 0);
+    return 0;
+}
+// poses of frames [first, first+count) as 16 floats each: poseR(9) poset(3) tracked iterations level_iters 0
+int slamhost_rg_history(void *rg, int first, int count, float *out) {
+    if (!rg || !out || first < 0 || count < 0) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    if (first + count > r->frames_done || r->frames_done - first > RG::HISTORY_CAP) return RGBDSLAM_E_LIMIT;
+    FACADE_TRY(r->Sync());
+    for (int k = 0; k < count; k++) memcpy(out + 16 * (size_t)k, r->history_host(first + k), 64);
     return 0;
 }
 int slamhost_rg_set_index_buffer(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     ((RG *)rg)->_predicted_frame->use_index_buffer = on != 0;
+    if (on) return slamhost_rg_set_fused(rg, 0);               // an explicit GL_QUADS index buffer only exists unfused
     return 0;
 }
 int slamhost_rg_set_plane_range(void *rg, int lo, int hi) {
@@ -641,9 +765,19 @@ int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, 
                                     size_t depth_pitch, size_t bgr_pitch, int *tracked) {
     if (!rg || !depth_dev || !bgr_dev || count < 0) return RGBDSLAM_E_ARG;
     int ok = 0;
-    FACADE_TRY(for (int k = 0; k < count; k++) {
-        ((RG *)rg)->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
-        if (((RG *)rg)->Step() != 0) ok++;
+    RG *r = (RG *)rg;
+    FACADE_TRY(if (r->fused) {
+        r->Sync();
+        long before = r->tracked_total;
+        for (int k = 0; k < count; k++) {
+            r->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
+            r->StepAsync();
+        }
+        r->Sync();                                             // the only host<->device sync of the sequence
+        ok = (int)(r->tracked_total - before);
+    } else for (int k = 0; k < count; k++) {
+        r->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
+        if (r->Step() != 0) ok++;
     });
     if (tracked) *tracked = ok;
     return 0;

@@ -90,6 +90,10 @@ public:
     // decoded images: host buffers (uploaded here) or device-resident ones (used in place).
     void LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);
     void LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    // fused pipeline: when gradient buffers are attached, LoadFrame* runs rgbdslam_frame_preprocess
+    // (one kernel for Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
+    void AttachGradients(float *gx, float *gy, size_t pitch) { _gx = gx; _gy = gy; _gpitch = pitch; }
+    bool has_gradients() const { return _gx != nullptr; }
     const uint16_t *depth() const { return _depth_cur; }
     size_t depth_pitch() const { return _depth_pitch; }
 private:
@@ -98,6 +102,8 @@ private:
     DevBuf<uint8_t> _color_dev_test;
     const uint16_t *_depth_cur = nullptr;
     size_t _depth_pitch = 0;
+    float *_gx = nullptr, *_gy = nullptr;
+    size_t _gpitch = 0;
 };
 
 // ---- D1/Frame.h:188-282 -----------------------------------------------------------------------
@@ -111,6 +117,12 @@ public:
     void InitMask();                                              // Frame.cpp:361-370
     void ProjectMask(float *pose);                                // Frame.cpp:372-383
     void ProjectLabel(float *pose_loc, float *pose_glob, float *Equations_dev, int nbPlans);  // Frame.cpp:385-405
+    // fused frame pipeline (include/rgbdslam.h "fused frame pipeline"): the same methods as one
+    // launch each, poses taken from the device-resident block, model set A -> B -> A
+    void ReseedFused(const rgbdslam_pose_block *pb, int force, OffLineFrame *frame);       // Cpy + InitMask
+    void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar);              // Transform..ProjectLabel gather
+    void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
+    void MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame);
     float *getVMap() { return _VMap_dev.p; }
     float *getNMap() { return _NMap_dev.p; }
     float *getRGB() { return _RGB_dev.p; }
@@ -120,6 +132,7 @@ public:
 private:
     rgbdslam_ctx *_ctx;
     DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev, _tex;
+    DevBuf<float> _VMap_alt, _RGB_alt;   // model set B of the fused pipeline
     DevBuf<uint8_t> _mask_a, _mask_b, _label_a, _label_b;
     DevBuf<uint32_t> _Index_dev;
     DevBuf<uint64_t> _zbuf;
@@ -148,6 +161,7 @@ public:
     ~Graph();
     bool AddPrimitive(Primitive *Prim);                           // Graph.h:100-116
     void Update(PredictedFrame *frame, float *pose);              // Graph.cpp:50-95
+    void UpdateTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb);   // same, pose from the device block
     void Clear();
     std::vector<Primitive *> _nodes;
     int _SizeVBUFF[2];
@@ -160,6 +174,7 @@ private:
     std::vector<DevBuf<uint64_t> *> _data_Claim_dev;
     DevBuf<void *> _BumpTab, _RGBTab, _MaskTab, _ParamTab, _ClaimTab;
     bool _tables_built = false;
+    void build_tables();
     uint32_t _stamp = 0;
 };
 
@@ -178,6 +193,15 @@ public:
     void CreatePrimitives(float *pose);                            // RG.cpp:699-793
     // one pass of display() (GP-demo.cpp:138-296): 2 = model seeded, 1 = tracked, 0 = lost
     int Step();
+    // fused pipeline (default): the whole pass is enqueued without a host sync; the pose, status and
+    // iteration counts stay on the device until Sync().  Returns 2 for the seeding frame, else 1.
+    int StepAsync();
+    int Sync();                                                    // -> last frame's status: 1 tracked / 0 lost
+    bool fused = true;
+    static const int HISTORY_CAP = 8192;                           // per-frame pose ring (16 floats each)
+    int frames_done = 0;
+    long tracked_total = 0;                                        // frames tracked so far (as of the last Sync)
+    const float *history_host(int frame_index);                    // valid after Sync(); frame_index in the last HISTORY_CAP
 
     OffLineFrame *_frame;
     PredictedFrame *_predicted_frame;
@@ -200,6 +224,11 @@ private:
     DevBuf<float> _intr_dev, _Rcurr_dev, _tcurr_dev, _img1, _Gx, _Gy, _pose_state_dev, _trace_dev;
     DevBuf<int32_t> _status_dev;
     float *_pinned = nullptr;   // 24 floats pose state + 4 ints status
+    rgbdslam_pose_block *_pb_dev = nullptr, *_pb_host = nullptr;   // device block + pinned mirror
+    DevBuf<float> _history_dev;
+    float *_history_host = nullptr;
+    int _history_synced = 0;
+    rgbdslam_icp_params icp_params() const;
 };
 
 }  // namespace slam

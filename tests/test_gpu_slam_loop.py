@@ -21,12 +21,13 @@ def same(a, b, what):
     assert ok.all(), "%s: mismatch at %d of %d elements" % (what, (~ok).sum(), ok.size)
 
 
-def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True, index_buffer=False, noise=0.0):
+def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True, index_buffer=False, noise=0.0, fused=True):
     calib = synth.calib_for(n, m)
     seq = synth.sequence(frames, n, m, calib, noise_sigma=noise)
     eq, centers = synth.plane_equations()
     ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
     rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg.set_fused(fused)
     rg.set_device_loop(device_loop)
     rg.set_index_buffer(index_buffer)
     statuses = []
@@ -66,8 +67,14 @@ def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True,
     ref.close()
 
 
-def test_loop_small(pkg, orc, synth):
-    run_pair(pkg, orc, synth, 120, 160, frames=6, N_prim=512, planes_at=2)
+@pytest.mark.parametrize("fused", [True, False])
+def test_loop_small(pkg, orc, synth, fused):
+    run_pair(pkg, orc, synth, 120, 160, frames=6, N_prim=512, planes_at=2, fused=fused)
+
+
+def test_loop_odd_size_fused(pkg, orc, synth):
+    """Image sides that are no multiple of the 64x4 tiles / 8x8 blocks (halo and edge handling)."""
+    run_pair(pkg, orc, synth, 93, 131, frames=4, N_prim=256, planes_at=1)
 
 
 def test_loop_small_host_solve_and_index_buffer(pkg, orc, synth):
@@ -75,22 +82,26 @@ def test_loop_small_host_solve_and_index_buffer(pkg, orc, synth):
     run_pair(pkg, orc, synth, 96, 128, frames=4, N_prim=256, planes_at=1, device_loop=False, index_buffer=True)
 
 
-def test_loop_640x480(pkg, orc, synth):
+@pytest.mark.parametrize("fused", [True, False])
+def test_loop_640x480(pkg, orc, synth, fused):
     """Config 2 shape: TUM fr1/xyz-like 640x480 sequence, 3 planes of 1024x1024 Bump cells."""
-    run_pair(pkg, orc, synth, 480, 640, frames=5, N_prim=1024, planes_at=1)
+    run_pair(pkg, orc, synth, 480, 640, frames=5, N_prim=1024, planes_at=1, fused=fused, noise=0.001 if fused else 0.0)
 
 
 def test_loop_noisy(pkg, orc, synth):
     run_pair(pkg, orc, synth, 120, 160, frames=5, N_prim=512, planes_at=1, noise=0.001)
 
 
-def test_loop_track_loss_reseeds_model(pkg, orc, synth):
+@pytest.mark.parametrize("fused", [True, False])
+def test_loop_track_loss_reseeds_model(pkg, orc, synth, fused):
     """A frame from a far-away pose must report lost (RG.cpp:910-920), keep the pose and re-seed the
-    model from the input frame (GP-demo.cpp:189-196)."""
+    model from the input frame (GP-demo.cpp:189-196).  In the fused pipeline that decision is taken
+    on the device (kernels gated on the pose block)."""
     n, m = 120, 160
     calib = synth.calib_for(n, m)
     ref = orc.Slam(n, m, calib, N_prim=256, M_prim=256)
     rg = pkg.RG(n, m, calib, N_prim=256, M_prim=256)
+    rg.set_fused(fused)
     far = synth.euler_xyz(*np.deg2rad([14.0, -12.0, 9.0]))
     frames = [synth.render(np.eye(3), np.zeros(3), n, m, calib), synth.render(far, np.array([0.35, -0.3, 0.25]), n, m, calib),
               synth.render(far, np.array([0.35, -0.3, 0.25]), n, m, calib)]
@@ -136,3 +147,37 @@ def test_hip_path_reproduces_golden_fixture(pkg):
         same(sha(rg.buffer("Bump%d" % k)), g["sha_Bump%d" % k], "Bump%d" % k)
         same(sha(rg.buffer("RGBb%d" % k)), g["sha_RGBb%d" % k], "RGBb%d" % k)
     rg.close()
+
+
+def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth):
+    """run_device_sequence enqueues every frame without a host sync (pose history on the device);
+    the per-frame poses and the final model must equal the oracle's frame-by-frame loop, including
+    a tracking loss in the middle of the sequence."""
+    n, m, N_prim = 120, 160, 256
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(8, n, m, calib, noise_sigma=0.001)
+    far = synth.euler_xyz(*np.deg2rad([14.0, -12.0, 9.0]))
+    seq[4] = synth.render(far, np.array([0.35, -0.3, 0.25]), n, m, calib)      # lost here, re-seeded, then lost again going back
+    eq, centers = synth.plane_equations()
+    ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    ref.step(*seq[0]); rg.load_frame(*seq[0]); rg.step()
+    ref.set_planes(eq, centers); rg.set_planes(eq, centers)
+    want = []
+    for d, c in seq[1:]:
+        st = ref.step(d, c)
+        R, t = ref.pose()
+        want.append((st, R.copy(), t.copy()))
+    depth_t = [torch.from_numpy(d).cuda() for d, _ in seq[1:]]
+    bgr_t = [torch.from_numpy(c).cuda() for _, c in seq[1:]]
+    tracked = rg.run_device_sequence(depth_t, bgr_t)
+    assert tracked == sum(1 for st, _, _ in want if st != 0) and 0 < tracked < len(want)
+    hist = rg.history(1, len(want))
+    for k, (st, R, t) in enumerate(want):
+        assert int(hist[k, 12]) == (1 if st else 0), k
+        same(hist[k, :9], R, "frame %d poseR" % (k + 1))
+        same(hist[k, 9:12], t, "frame %d poset" % (k + 1))
+    for name in ("VMap", "NMap", "RGBD", "Mask", "Label", "Maskb0", "Bump1", "RGBb2"):
+        same(rg.buffer(name), ref.buffer(name), name)
+    rg.close()
+    ref.close()
