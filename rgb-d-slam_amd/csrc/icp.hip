@@ -129,35 +129,44 @@ __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr
 }
 
 // ---- 27-term block sum in the pairing of reduce<64> (D1/ICP.cu:28-48) -----------------------------
-// Reference tid = col*8 + row, lane = row*8 + col, so the tree's tid offsets 32,16,8,4,2,1 are the
-// lane bits 2,1,0,5,4,3.  A butterfly over those bits in that order leaves in every lane the same
-// bits as the tree leaves in v[0] (IEEE addition is commutative, the pairing is unchanged).
-// Instead of 27 independent butterflies (162 cross-lane moves) the terms are split between the two
-// partners at every level -- 14+7+4+2+1+1 = 29 moves -- and each lane ends with ONE finished term:
-//   term(lane) = 14*b2 + 7*b1 + 4*b0 + 2*b5 + b4,  valid unless (b0 & b5 & b4) or term == 27.
-template <int HALF, int XOR>
-__device__ __forceinline__ void fold_level(const float *in, int n_in, float *out, bool hi) {
-#pragma unroll
-    for (int k = 0; k < HALF; k++) {
-        float lo_v = in[k];
-        float hi_v = (HALF + k < n_in) ? in[HALF + k] : 0.0f;
-        float send = hi ? lo_v : hi_v;          // what the partner keeps
-        float keep = hi ? hi_v : lo_v;
-        out[k] = keep + __shfl_xor(send, XOR);
-    }
+// Reference tid = col*8 + row, lane = row*8 + col, so the tree's tid offsets 32,16,8 pair COLUMNS
+// c|c+4, c|c+2, c|c+1 of one image row (lanes of one 8-lane group) and the offsets 4,2,1 pair ROWS
+// r|r+4, r|r+2, r|r+1.  Column levels: three DPP row-shift adds per term (v_add_f32 with a lane
+// shift, no LDS, no select); the lanes with col == 0 then hold 8 row partials per term, which are
+// transposed through LDS so that lanes 0..26 finish one term each.  IEEE addition is commutative
+// and the pairing is the reference's, so the result has the bits of the serial tree.
+// row_shl:N -- lane i receives lane i+N of its 16-lane row (0 beyond the row)
+template <int N>
+__device__ __forceinline__ float add_shl(float v) {
+    int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true);
+    return v + __int_as_float(moved);
 }
-__device__ __forceinline__ float fold27(const float *v, int lane, int &term, bool &valid) {
-    float a[14], b[7], c[4], d[2], e[1];
-    bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1, b5 = lane & 32, b4 = lane & 16;
-    fold_level<14, 4>(v, 27, a, b2);
-    fold_level<7, 2>(a, 14, b, b1);
-    fold_level<4, 1>(b, 7, c, b0);
-    fold_level<2, 32>(c, 4, d, b5);
-    fold_level<1, 16>(d, 2, e, b4);
-    float r = e[0] + __shfl_xor(e[0], 8);
-    term = (b2 ? 14 : 0) + (b1 ? 7 : 0) + (b0 ? 4 : 0) + (b5 ? 2 : 0) + (b4 ? 1 : 0);
-    valid = term < 27 && !(b0 && b5 && b4);
-    return r;
+// tr = this wave's LDS scratch [27][8]; returns the finished sum of term `lane` in lanes 0..26
+__device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
+    const bool row_head = (lane & 7) == 0;
+    const int r = lane >> 3;
+    float x[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) x[k] = add_shl<4>(v[k]);      // level by level: independent DPP chains interleave
+#pragma unroll
+    for (int k = 0; k < 27; k++) x[k] = add_shl<2>(x[k]);
+#pragma unroll
+    for (int k = 0; k < 27; k++) x[k] = add_shl<1>(x[k]);
+    if (row_head) {
+#pragma unroll
+        for (int k = 0; k < 27; k++) tr[k * 8 + r] = x[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float out = 0.0f;
+    if (lane < 27) {
+        const float4 lo = *(const float4 *)(tr + lane * 8), hi = *(const float4 *)(tr + lane * 8 + 4);
+        float y0 = lo.x + hi.x, y1 = lo.y + hi.y, y2 = lo.z + hi.z, y3 = lo.w + hi.w;   // rows r | r+4
+        float z0 = y0 + y2, z1 = y1 + y3;                                              // rows r | r+2
+        out = z0 + z1;                                                                 // rows 0 | 1
+    }
+    return out;
 }
 
 // ---- one Gauss-Newton iteration: match + both reduction stages (+ solve) in ONE launch -----------
@@ -199,6 +208,7 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
 __global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void k_icp_iter(IcpIterArgs a) {
     __shared__ float part[ICP_MAX_WAVES][27];
+    __shared__ __attribute__((aligned(16))) float tr[ICP_MAX_WAVES][27 * 8];
     __shared__ float fin[27];
     __shared__ float solve_sh[2];
     __shared__ IcpState sst;          // snapshot of the loop state (or of the caller's R, t, intr)
@@ -268,9 +278,8 @@ void k_icp_iter(IcpIterArgs a) {
             for (int kk = 0; kk < 6; kk++)
 #pragma unroll
                 for (int l = kk; l < 7; l++) v[term++] = q.g[kk] * q.g[l] + q.c[kk] * q.c[l];   // ICP.cu:229
-            bool valid;
-            float sum = fold27(v, lane, term, valid);
-            if (valid && !(lane & 8)) part[wave][term] = sum;
+            float sum = fold27(v, lane, tr[wave]);
+            if (lane < 27) part[wave][lane] = sum;
         }
         __syncthreads();
         if (wave == 0 && lane < 27) {
