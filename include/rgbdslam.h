@@ -177,7 +177,12 @@ int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bl
                            const float *VMap_in, const float *RGBD_in, const uint8_t *Mask_in,
                            const uint8_t *Label_in, uint64_t *zbuf, float *VMap_out, float *RGBD_out,
                            uint8_t *Mask_out, uint8_t *Label_out, float thresh, float znear,
-                           float zfar, int n, int m);
+                           float zfar, int n, int m,
+                           /* optional (frame_VMap != NULL): when the block says LOST, the same launch
+                            * performs rgbdslam_model_reseed on set "in" (VMap_in, NMap_reseed, RGBD_in,
+                            * Mask_in are then written) -- GP-demo.cpp:189-193 without an extra launch */
+                           const float *frame_VMap, const float *frame_NMap, const float *frame_RGB,
+                           const uint16_t *depth, size_t depth_pitch_bytes, float *NMap_reseed);
 /* ComputeNormal of ReadFrame (Frame.cpp:242) + Segment_cu (Frame.cpp:395).  The result is left in
  * Label_swap (one pass when nbPlans == 0, three otherwise: always an odd number of swaps). */
 int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,

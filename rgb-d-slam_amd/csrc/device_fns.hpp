@@ -128,13 +128,19 @@ __device__ __forceinline__ float dist3(F3 a, F3 b) {
     float x = a.x - b.x, y = a.y - b.y, z = a.z - b.z;
     return __builtin_sqrtf((x * x + y * y) + z * z);
 }
+__device__ __forceinline__ float dist3_sq(F3 a, F3 b) {
+    float x = a.x - b.x, y = a.y - b.y, z = a.z - b.z;
+    return (x * x + y * y) + z * z;
+}
+// max of the six edge lengths > thresh.  sqrtf is correctly rounded, hence monotonic:
+// max_i sqrt(s_i) == sqrt(max_i s_i) bit for bit, so one square root decides.
 __device__ __forceinline__ bool quad_trimmed(F3 a, F3 b, F3 c, F3 d, float thresh) {
-    float mx = fmaxf(dist3(a, b), dist3(a, c));
-    mx = fmaxf(dist3(a, d), mx);
-    mx = fmaxf(dist3(b, c), mx);
-    mx = fmaxf(dist3(b, d), mx);
-    mx = fmaxf(dist3(c, d), mx);
-    return mx > thresh;
+    float mx = fmaxf(dist3_sq(a, b), dist3_sq(a, c));
+    mx = fmaxf(dist3_sq(a, d), mx);
+    mx = fmaxf(dist3_sq(b, c), mx);
+    mx = fmaxf(dist3_sq(b, d), mx);
+    mx = fmaxf(dist3_sq(c, d), mx);
+    return __builtin_sqrtf(mx) > thresh;
 }
 
 // ---- compute rasteriser ---------------------------------------------------------------

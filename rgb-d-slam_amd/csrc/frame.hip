@@ -89,6 +89,25 @@ void k_frame_preprocess(const uint16_t *__restrict__ depth, size_t dpitch, const
     *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
 }
 
+struct ReseedArgs {                                  // model := input frame (set A), used when the tracker reports a loss
+    const float *fV, *fN, *fRGB;
+    const uint16_t *depth;
+    size_t dpitch;
+    float *VMap, *NMap, *RGBD;
+    uint8_t *Mask;
+};
+__device__ __forceinline__ void reseed_pixel(const ReseedArgs &r, const CalibV &c, int i, int j, int n, int m) {
+    size_t idx = (size_t)i * m + j;
+    F3 v = ld3(r.fV, idx), nn = ld3(r.fN, idx), col = ld3(r.fRGB, idx);
+    st3(r.VMap, idx, v.x, v.y, v.z);
+    st3(r.NMap, idx, nn.x, nn.y, nn.z);
+    float4 o;
+    o.x = col.x; o.y = col.y; o.z = col.z;
+    o.w = zbuff_w(((const uint16_t *)((const char *)r.depth + (size_t)(n - i - 1) * r.dpitch))[j], c);
+    *(float4 *)(r.RGBD + 4 * idx) = o;
+    r.Mask[idx] = (o.w == 0.0f) ? 10 : 11;                         // Kernel.cu:624-627
+}
+
 // ---- PredictedFrame::Cpy + InitMask (D1/Frame.cpp:335-370): model := input frame --------------------
 // runs when forced (first frame) or when the tracker reported a loss (GP-demo.cpp:164-167,189-193)
 __global__ void k_model_reseed(const rgbdslam_pose_block *__restrict__ pb, int force, const float *__restrict__ fV,
@@ -99,15 +118,8 @@ __global__ void k_model_reseed(const rgbdslam_pose_block *__restrict__ pb, int f
     if (!force && pb_tracked(pb)) return;
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
-    size_t idx = (size_t)i * m + j;
-    F3 v = ld3(fV, idx), nn = ld3(fN, idx), col = ld3(fRGB, idx);
-    st3(VMap, idx, v.x, v.y, v.z);
-    st3(NMap, idx, nn.x, nn.y, nn.z);
-    float4 o;
-    o.x = col.x; o.y = col.y; o.z = col.z;
-    o.w = zbuff_w(((const uint16_t *)((const char *)depth + (size_t)(n - i - 1) * dpitch))[j], c);
-    *(float4 *)(RGBD + 4 * idx) = o;
-    Mask[idx] = (o.w == 0.0f) ? 10 : 11;                           // Kernel.cu:624-627
+    ReseedArgs r = {fV, fN, fRGB, depth, dpitch, VMap, NMap, RGBD, Mask};
+    reseed_pixel(r, c, i, j, n, m);
 }
 
 // ---- PredictedFrame::Transform + the GL draw (Frame.cpp:281-298, GP-demo.cpp:98-113) ------------------
@@ -115,11 +127,16 @@ __global__ void k_model_reseed(const rgbdslam_pose_block *__restrict__ pb, int f
 // trimmed (QuadTrimFrameKernel, on the warped vertices like the reference) and z-buffered.
 __device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) { return is_zero3(v) ? v : xf_point(P, v); }
 
+// grid over n x m pixels: quad (i, j) for i < n-1, j < m-1; when the tracker lost the frame the same
+// grid re-seeds the model instead (GP-demo.cpp:189-193) -- no separate launch that usually does nothing.
 __global__ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
                                unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
-                               int n, int m) {
-    if (!pb_tracked(pb)) return;
+                               ReseedArgs rs, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (!pb_tracked(pb)) {
+        if (rs.fV && i < n && j < m) reseed_pixel(rs, c, i, j, n, m);
+        return;
+    }
     if (i > n - 2 || j > m - 2) return;
     const float *P = pb->P_rel;
     uint32_t q = (uint32_t)(i * (m - 1) + j), id[4];
@@ -284,7 +301,8 @@ extern "C" int rgbdslam_model_reseed(rgbdslam_ctx *ctx, const rgbdslam_pose_bloc
 extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
                                       const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
                                       float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
-                                      float znear, float zfar, int n, int m) {
+                                      float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
+                                      const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed) {
     if (!ctx || !pose_block_dev || !VMap_in || !RGBD_in || !Mask_in || !Label_in || !zbuf || !VMap_out || !RGBD_out ||
         !Mask_out || !Label_out)
         return RGBDSLAM_E_ARG;
@@ -292,8 +310,12 @@ extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_blo
         return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x3FFFFFFFu) return RGBDSLAM_E_LIMIT;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    KLAUNCH(ctx, k_predict_draw, grid2d(n - 1, m - 1), block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
-            ctx->calib, znear, zfar, n, m);
+    // lost frame: the draw grid re-seeds set "in" from the input frame (all-or-nothing: NULL frame_VMap = never)
+    if (frame_VMap && (!frame_NMap || !frame_RGB || !depth || !NMap_reseed || depth_pitch < 2 * (size_t)m)) return RGBDSLAM_E_ARG;
+    ReseedArgs rs = {frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, const_cast<float *>(VMap_in), NMap_reseed,
+                     const_cast<float *>(RGBD_in), const_cast<uint8_t *>(Mask_in)};
+    KLAUNCH(ctx, k_predict_draw, grid2d(n, m), block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
+            ctx->calib, znear, zfar, rs, n, m);
     KLAUNCH(ctx, k_predict_resolve, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
             (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());

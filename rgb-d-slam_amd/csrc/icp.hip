@@ -9,7 +9,7 @@
 // (D1/ICP.cu:50-70): the 27 sums are bit-identical to a serial restatement of the reference.
 #include "common.hpp"
 
-#define ICP_MAX_WAVES 10  // waves (= 8x8 blocks in flight) per workgroup: 640x480 has 9.4 blocks per chain -> one balanced round
+#define ICP_MAX_WAVES 5   // waves (= 8x8 blocks in flight) per workgroup: 640x480 has 9.4 blocks per chain -> two balanced rounds
 #define ICP_TAIL_TERMS ((27 + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES)   // terms per wave in the tail
 #define ICP_TICKET_GROUP 16
 #define ICP_TICKET_WORDS (32 * (1 + 512 / ICP_TICKET_GROUP))
@@ -196,16 +196,29 @@ struct IcpIterArgs {
     float thr_alpha, thr_tr;
     float *trace;
     long long *timing;                               // optional debug: phase time stamps (wall_clock64, 10 ns ticks)
+    // track_frame path: the first launch builds the loop state itself (k_icp_begin), the last one
+    // appends the track-loss test, the commit and the display() pose algebra (k_icp_end)
+    int first_launch, final_launch;
+    float intr4[4];
+    float *pose_state_rw;
+    int32_t *status;
+    rgbdslam_pose_block *pb;
+    float *history;
+    int frame_index;
 };
 
 // Collective over the calling workgroup (>= 2 waves, every thread must call it): wave 1 evaluates the
 // determinant test, thread 0 the Cholesky solve and the pose update.  st = working copy of the state
 // (LDS), out = device-resident state it is committed to, sh = 2 floats of LDS.
+struct IcpEndArgs { float *pose_state; int32_t *status; rgbdslam_pose_block *pb; float *history; int frame_index; };
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
-                                               int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh);
+                                               int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
+                                               const IcpEndArgs *end);
+__device__ __forceinline__ void icp_begin_step(IcpState *st, const float *pose_state, const float *intr4);
+__device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArgs &e);
 
 // 6 waves per SIMD (<= 80 VGPRs): two 10-wave workgroups per CU, so all 512 chains are resident at once
-__global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6)))
+__global__ __launch_bounds__(64 * ICP_MAX_WAVES)
 void k_icp_iter(IcpIterArgs a) {
     __shared__ float part[ICP_MAX_WAVES][27];
     __shared__ __attribute__((aligned(16))) float tr[ICP_MAX_WAVES][27 * 8];
@@ -228,8 +241,15 @@ void k_icp_iter(IcpIterArgs a) {
         float *dst = (float *)&sst;
         if (a.state) {
             const float *src = (const float *)a.state;
-            if (lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
             if (a.pose_state && lane < 24) spose[lane] = a.pose_state[lane];
+            if (!a.first_launch) {
+                if (lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane == 0) icp_begin_step(&sst, spose, a.intr4);   // RG.cpp:832-835,851-852
+            }
         } else {
             if (lane < 9) sst.Rcurr[lane] = a.R[lane];
             else if (lane < 12) sst.tcurr[lane - 9] = a.t[lane - 9];
@@ -250,7 +270,13 @@ void k_icp_iter(IcpIterArgs a) {
     };
     if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
     __syncthreads();
-    if (sst.fail || (a.iter > 0 && sst.cvg)) return;  // converged / failed earlier: the whole grid leaves
+    if (sst.fail || (a.iter > 0 && sst.cvg)) {        // converged / failed earlier: the whole grid leaves
+        if (a.final_launch && t == 0 && threadIdx.x == 0) {
+            IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
+            icp_end_step(&sst, e);
+        }
+        return;
+    }
 
     float acc = 0.0f;                                 // wave 0, lanes 0..26: running chain sum (ICP.cu:56-58)
     for (int r = 0; r < rounds; r++) {
@@ -349,7 +375,11 @@ void k_icp_iter(IcpIterArgs a) {
     long long ts4 = a.timing ? wall_clock64() : 0;
     if (threadIdx.x <= (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) a.ticket[32 * threadIdx.x] = 0u;   // ready for the next launch
     __syncthreads();
-    if (a.do_solve) icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh);
+    if (a.do_solve) {
+        IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
+        icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh,
+                       a.final_launch ? &e : nullptr);
+    }
     if (a.timing && threadIdx.x == 0) {
         a.timing[1] = ts0; a.timing[2] = ts1; a.timing[3] = ts2; a.timing[4] = ts3; a.timing[5] = ts4; a.timing[6] = wall_clock64();
     }
@@ -486,15 +516,18 @@ __device__ void d_set_rt_curr(IcpState *st, const float *ps) {
     st->tcurr[0] = tmp[0] + st->tinv[0]; st->tcurr[1] = tmp[1] + st->tinv[1]; st->tcurr[2] = tmp[2] + st->tinv[2];
 }
 
-__global__ void k_icp_begin(IcpState *st, const float *pose_state, CalibV c, int32_t *status) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void icp_begin_step(IcpState *st, const float *pose_state, const float *intr4) {
     float tmp[3];
     d_inverse3(pose_state, st->Rinv);                         // RG.cpp:834
     d_mat3_vec(st->Rinv, pose_state + 9, tmp);                // RG.cpp:835
     st->tinv[0] = -tmp[0]; st->tinv[1] = -tmp[1]; st->tinv[2] = -tmp[2];
-    for (int k = 0; k < 4; k++) st->intr[k] = c.v[k];
+    for (int k = 0; k < 4; k++) st->intr[k] = intr4[k];
     st->cvg = 0; st->fail = 0; st->iters = 0; st->lvl_iters = 0;
     d_set_rt_curr(st, pose_state);
+}
+__global__ void k_icp_begin(IcpState *st, const float *pose_state, CalibV c, int32_t *status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    icp_begin_step(st, pose_state, c.v);
     status[0] = 0; status[1] = 0;
 }
 
@@ -534,7 +567,8 @@ __device__ __forceinline__ void icp_pose_update(IcpState *st, const float *x, co
 }
 
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
-                                               int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh) {
+                                               int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
+                                               const IcpEndArgs *end) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float x[6];
     int llt_fail = 0;
@@ -559,6 +593,7 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
     }
     *out = loc;
+    if (end) icp_end_step(&loc, *end);
 }
 
 // stand-alone solve for the row-sharded path (launch with 128 threads): sums = sum over `parts`
@@ -579,7 +614,7 @@ void k_icp_solve(IcpState *st, const float *__restrict__ gathered, int parts, co
     }
     __syncthreads();
     if (sst.fail || (iter > 0 && sst.cvg)) return;
-    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh);
+    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh, nullptr);
 }
 
 __device__ __forceinline__ void d_pack_pose(const float *R, const float *t, float *P) {   // GP-demo.cpp:206-211
@@ -591,9 +626,12 @@ __device__ __forceinline__ void d_pack_pose(const float *R, const float *t, floa
 
 // pb (optional): pose_state/status are the block's own fields; the display() pose algebra is
 // appended (GP-demo.cpp:201-211,225-236) and the previous pose advanced (244-245 / 192-193).
-__global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status, rgbdslam_pose_block *pb, float *history,
-                          int frame_index) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArgs &e) {
+    float *pose_state = e.pose_state;
+    int32_t *status = e.status;
+    rgbdslam_pose_block *pb = e.pb;
+    float *history = e.history;
+    const int frame_index = e.frame_index;
     status[1] = st->iters;
     status[2] = st->lvl_iters;
     int ok = !st->fail;
@@ -638,6 +676,12 @@ __global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status, rgbd
         }
     }
 }
+__global__ void k_icp_end(IcpState *st, float *pose_state, int32_t *status, rgbdslam_pose_block *pb, float *history,
+                          int frame_index) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    IcpEndArgs e = {pose_state, status, pb, history, frame_index};
+    icp_end_step(st, e);
+}
 
 // =================================================================================================
 // C ABI
@@ -680,7 +724,8 @@ struct IcpMaps {
 static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, const float *t, const IcpMaps &mp,
                        float distThres, float angleThres, int n, int m, int fact, int br_lo, int br_hi, float *sums,
                        int32_t *corr, IcpState *state, const float *pose_state, int do_solve, int lvl, int iter, int max_iter,
-                       float thr_alpha, float thr_tr, float *trace) {
+                       float thr_alpha, float thr_tr, float *trace, int first_launch = 0, int final_launch = 0,
+                       const IcpEndArgs *end = nullptr) {
     int gr = div_up(n / fact, 8), gc = div_up(m / fact, 8);   // D1/ICP.cu:260-261
     if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
     if (br_lo < 0) br_lo = 0;
@@ -701,6 +746,10 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.state = state; a.pose_state = pose_state; a.do_solve = do_solve; a.lvl = lvl; a.iter = iter; a.max_iter = max_iter;
     a.thr_alpha = thr_alpha; a.thr_tr = thr_tr; a.trace = trace;
     a.timing = ctx->icp_timing_dev;
+    a.first_launch = first_launch; a.final_launch = final_launch;
+    for (int k = 0; k < 4; k++) a.intr4[k] = ctx->calib.v[k];
+    a.pose_state_rw = end ? end->pose_state : nullptr; a.status = end ? end->status : nullptr;
+    a.pb = end ? end->pb : nullptr; a.history = end ? end->history : nullptr; a.frame_index = end ? end->frame_index : 0;
     KLAUNCH(ctx, k_icp_iter, dim3(a.nchain), dim3(64 * a.nwaves), a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -752,19 +801,23 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
     if (rc) return rc;
     IcpState *st = ctx->icp_state;
     IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
-    KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
+    // track_frame: begin and end ride on the first and the last iteration launch
+    const bool ride = pose_block != nullptr;
+    IcpEndArgs end = {pose_state_dev, status_dev, pose_block, history, frame_index};
+    if (!ride) KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
     int fact = 1 << (prm->lvl - 1);                            // RG.cpp:832
     for (int lvl = prm->lvl - 1; lvl > -1; lvl--) {
         int n_it = prm->max_iter[lvl] + 2;                     // iter = 0 .. max_iter+1 (RG.cpp:889)
         for (int iter = 0; iter < n_it; iter++) {
+            int first = ride && lvl == prm->lvl - 1 && iter == 0, last = ride && lvl == 0 && iter == n_it - 1;
             rc = launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, fact, 0, 1 << 30,
                              ctx->outbuf_dev, nullptr, st, pose_state_dev, 1, lvl, iter, prm->max_iter[lvl],
-                             prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev);
+                             prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev, first, last, ride ? &end : nullptr);
             if (rc) return rc;
         }
         fact /= 2;
     }
-    KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev, pose_block, history, frame_index);
+    if (!ride) KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev, pose_block, history, frame_index);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -285,9 +285,12 @@ void PredictedFrame::ReseedFused(const rgbdslam_pose_block *pb, int force, OffLi
     check(rgbdslam_model_reseed(_ctx, pb, force, frame->getVMap(), frame->getNMap(), frame->getRGB(), frame->depth(),
                                 frame->depth_pitch(), _VMap_dev.p, _NMap_dev.p, _RGB_dev.p, _Mask_dev, _n, _m), "model_reseed");
 }
-void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar) {
+void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *frame) {
+    // frame != null: a lost frame re-seeds the model inside the same launch (Cpy + InitMask, GP-demo.cpp:190-191)
     check(rgbdslam_model_predict(_ctx, pb, _VMap_dev.p, _RGB_dev.p, _Mask_dev, _Label_dev, _zbuf.p, _VMap_alt.p, _RGB_alt.p,
-                                 _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m), "model_predict");
+                                 _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m, frame ? frame->getVMap() : nullptr,
+                                 frame ? frame->getNMap() : nullptr, frame ? frame->getRGB() : nullptr,
+                                 frame ? frame->depth() : nullptr, frame ? frame->depth_pitch() : 0, _NMap_dev.p), "model_predict");
 }
 void PredictedFrame::NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans) {
     // projected labels are in _Label_dev_swap; an odd number of passes brings them back to _Label_dev
@@ -599,8 +602,8 @@ int RG::StepAsync() {
     check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _Gx.p, pitch, _Gy.p, pitch,
                                _predicted_frame->getVMap(), _predicted_frame->getNMap(), _predicted_frame->getRGB(), n, m, _pb_dev,
                                _history_dev.p, frames_done % HISTORY_CAP), "track_frame");   // GP-demo.cpp:189 + 201-245
-    _predicted_frame->ReseedFused(_pb_dev, 0, _frame);                              // GP-demo.cpp:190-191 (only if lost)
-    _predicted_frame->PredictFused(_pb_dev, Znear, Zfar);                           // GP-demo.cpp:215-237 + ProjectLabel gather
+    // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
+    _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
     _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);       // Frame.cpp:242 + 395
     _predicted_frame->MergeFused(_pb_dev, _frame);                                  // GP-demo.cpp:249
     _graph->UpdateTracked(_predicted_frame, _pb_dev);                               // GP-demo.cpp:260

@@ -120,7 +120,7 @@ public:
     // fused frame pipeline (include/rgbdslam.h "fused frame pipeline"): the same methods as one
     // launch each, poses taken from the device-resident block, model set A -> B -> A
     void ReseedFused(const rgbdslam_pose_block *pb, int force, OffLineFrame *frame);       // Cpy + InitMask
-    void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar);              // Transform..ProjectLabel gather
+    void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *reseed_from);   // Transform..ProjectLabel gather
     void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
     void MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame);
     float *getVMap() { return _VMap_dev.p; }
