@@ -229,6 +229,15 @@ int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *RGBA, float
                               const uint16_t *Bump, const uint8_t *RGB_bump, const uint8_t *Mask,
                               const float *param_dev, int n, int m, int lvl);
 
+/* The same decode for planes [plane_lo, plane_hi) in ONE launch (lvl = 1, m % 4 == 0): the tables are
+ * device arrays of per-plane device pointers like Update_cu's; outputs one buffer per plane (the
+ * reference keeps one VBO triple per Primitive, Primitive.h:60-66).  For models of hundreds of
+ * planes (BASELINE configs[2]) where one launch per plane would be launch-bound. */
+int rgbdslam_vertex_from_bump_batch(rgbdslam_ctx *ctx, float **VMapTab, float **RGBATab,
+                                    float **MaskOutTab, uint16_t **BumpTab, uint8_t **RGBTab,
+                                    uint8_t **MaskTab, float **ParamTab, int plane_lo, int plane_hi,
+                                    int n, int m);
+
 /* ---- stage 5: prediction ------------------------------------------------------------------ */
 /* Kernel.cuh:19  void TransformVertexMap(float *VMap, float *RGBD, int n, int m)  (uses pose) */
 int rgbdslam_transform_vertex_map(rgbdslam_ctx *ctx, float *VMap, float *RGBD, int n, int m);

@@ -347,6 +347,116 @@ def test_update_and_decode(ctx, orc, pair, synth):
         same(host(v), rv)
         same(host(c), rc)
         same(host(k4), rk)
+    # whole-model decode in one launch (planes 1..2 of 3), 4 cells per lane
+    outs = [[torch.full((N_prim, N_prim, ch), -7.0, device="cuda") for _ in range(3)] for ch in (3, 4, 4)]
+    otabs = [_ptr_table(x) for x in outs]
+    ctx.vertex_from_bump_batch(otabs[0], otabs[1], otabs[2], tabs[0], tabs[1], tabs[2], tabs[3], 1, 3, N_prim, N_prim)
+    assert float(outs[0][0].min()) == -7.0 and float(outs[0][0].max()) == -7.0      # plane 0 is outside [1, 3)
+    for k in (1, 2):
+        rv, rc, rk = orc.vertex_from_bump(bumps[k], rgbs[k], masks[k], params[k], 1)
+        same(host(outs[0][k]), rv)
+        same(host(outs[1][k]), rc)
+        same(host(outs[2][k]), rk)
+
+
+def test_decode_all_byte_and_word_values(ctx, orc):
+    """Bump codec decode over every u8 colour/mask value and a sweep of u16 values: pins the claim
+    that the f32 divisions used on the device equal the reference's divide-in-double-then-round."""
+    N = 256
+    rng = np.random.default_rng(9)
+    bump = rng.integers(0, 65536, (N, N, 3)).astype(np.uint16)
+    bump[:, :, 0] = (np.arange(N * N).reshape(N, N) * 1) % 65536            # all 65536 values of the first channel
+    rgbb = rng.integers(0, 256, (N, N, 3)).astype(np.uint8)
+    rgbb[0, :, 0] = np.arange(256)
+    mask = (np.arange(N * N).reshape(N, N) % 256).astype(np.uint8)
+    param = np.array([0.3, -0.5, 0.81, -1.7, 500.0, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5], np.float32)
+    g = [dev(bump), dev(rgbb), dev(mask), dev(param)]
+    outs = [[torch.empty(N, N, ch, device="cuda")] for ch in (3, 4, 4)]
+    ctx.vertex_from_bump_batch(_ptr_table(outs[0]), _ptr_table(outs[1]), _ptr_table(outs[2]), _ptr_table([g[0]]), _ptr_table([g[1]]),
+                               _ptr_table([g[2]]), _ptr_table([g[3]]), 0, 1, N, N)
+    rv, rc, rk = orc.vertex_from_bump(bump, rgbb, mask, param, 1)
+    same(host(outs[0][0]), rv)
+    same(host(outs[1][0]), rc)
+    same(host(outs[2][0]), rk)
+
+
+def test_preprocess_fused_all_byte_values(ctx, orc, synth):
+    """rgbdslam_frame_preprocess (one kernel) == cpy_char3 + vertex_map_kinect + compute_normal +
+    intensity + Sobel of the oracle, on an image holding every byte value and holes, odd size."""
+    n, m = 61, 150
+    calib = synth.calib_for(n, m)
+    ctx.set_calibration_matrix(calib)
+    rng = np.random.default_rng(4)
+    d, _ = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    d[rng.random((n, m)) < 0.05] = 0
+    c = rng.integers(0, 256, (n, m, 3)).astype(np.uint8)
+    c.reshape(-1)[:256] = np.arange(256)
+    v = torch.empty(n, m, 3, device="cuda"); nm = torch.empty(n, m, 3, device="cuda"); rgb = torch.empty(n, m, 3, device="cuda")
+    gx = torch.empty(n, m, device="cuda"); gy = torch.empty(n, m, device="cuda")
+    import ctypes as C
+    gd, gcol = dev(d), dev(c)
+    rc = ctx.lib.rgbdslam_frame_preprocess(ctx._h, C.c_void_p(gd.data_ptr()), C.c_size_t(2 * m), C.c_void_p(gcol.data_ptr()),
+                                           C.c_size_t(3 * m), C.c_void_p(v.data_ptr()), C.c_void_p(nm.data_ptr()),
+                                           C.c_void_p(rgb.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_size_t(4 * m),
+                                           C.c_void_p(gy.data_ptr()), C.c_size_t(4 * m), n, m)
+    assert rc == 0
+    ctx.synchronize()
+    rv = orc.vertex_map_kinect(d, calib)
+    rrgb = orc.cpy_char3(c)
+    _, rgx, rgy = orc.intensity_sobel(rrgb)
+    same(host(v), rv)
+    same(host(rgb), rrgb)
+    same(host(nm), orc.compute_normal(rv))
+    same(host(gx), rgx)
+    same(host(gy), rgy)
+    ctx.set_calibration_matrix(synth.TUM_CALIB)
+
+
+def test_icp_row_bands_and_gathered_solve(ctx, pkg, orc, pair):
+    """Row-sharded ICP on one GPU: the two 'ranks' are two band launches.  Each band's 27 sums equal
+    the oracle's two-stage reduction restricted to the band's blocks; the rank-ordered total drives
+    the solve; the loop converges to the single-GPU pose within 1e-5 (north_star tolerance)."""
+    import ctypes as C
+    n, m = 480, 640
+    calib = pair["calib"]
+    ctx.set_calibration_matrix(calib)
+    ctx.alloc_buffers(60, 80)
+    prm = pkg.icp_params()
+    I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+    g = {k: dev(pair[k]) for k in ("v0", "n0", "rgbd0", "v1", "n1", "rgb1", "gx1", "gy1")}
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib = ctx.lib
+    state = dev(np.concatenate([I, z, I, z]).astype(np.float32)); status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    gathered = torch.zeros(2, 27, device="cuda")
+    sin20 = float(np.sin(np.deg2rad(20.0)))
+    assert lib.rgbdslam_align_begin(ctx._h, p(state), p(status)) == 0
+    checked = False
+    for lvl in (2, 1, 0):
+        fact = 1 << lvl
+        gr, gc = orc.icp_grid(n, m, fact)
+        split = gr // 2 + 1                                        # uneven bands
+        for it in range(prm.max_iter[lvl] + 2):
+            for r, (lo, hi) in enumerate(((0, split), (split, gr))):
+                rc = lib.rgbdslam_align_band_system(ctx._h, C.byref(prm), p(g["v1"]), p(g["n1"]), p(g["rgb1"]), p(g["gx1"]),
+                                                    C.c_size_t(4 * m), p(g["gy1"]), C.c_size_t(4 * m), p(g["v0"]), p(g["n0"]),
+                                                    p(g["rgbd0"]), n, m, lvl, it, lo, hi, C.c_void_p(gathered[r].data_ptr()))
+                assert rc == 0
+            if not checked:                                        # first iteration: identity estimate -> compare with the oracle
+                buf, _ = orc.icp_match(calib[:4], I, z, pair["v1"], pair["n1"], pair["rgb1"], pair["gx1"], pair["gy1"], pair["v0"],
+                                       pair["n0"], pair["rgbd0"], 0.05, sin20, fact)
+                b3 = buf.reshape(27, gc, gr)
+                for r, (lo, hi) in enumerate(((0, split), (split, gr))):
+                    local = np.ascontiguousarray(b3[:, :, lo:hi]).reshape(27, -1)
+                    same(host(gathered[r]), orc.icp_reduce(local))
+                checked = True
+            assert lib.rgbdslam_align_solve_gathered(ctx._h, C.byref(prm), p(gathered), 2, p(state), lvl, it, None) == 0
+    assert lib.rgbdslam_align_end(ctx._h, p(state), p(status)) == 0
+    ctx.synchronize()
+    ok, R, t, trace = orc.align_gauss_newton(orc.icp_params(), calib[:4], pair["v1"], pair["n1"], pair["rgb1"], pair["v0"], pair["n0"],
+                                             pair["rgbd0"], I, z, I, z)
+    s = host(state)
+    assert ok and int(status[0]) == 1
+    assert np.abs(s[:9] - R).max() <= 1e-5 and np.abs(s[9:12] - t).max() <= 1e-5
 
 
 def test_update_plane_partition(ctx, orc, pair, synth):
