@@ -40,11 +40,86 @@ def algo_bytes(kernel, n, m, level_iters):
     if kernel == "k_icp_iter":
         # 80 B per sampled model pixel per executed iteration, all three levels summed
         return sum(80 * (n // f) * (m // f) * it for f, it in zip((1, 2, 4), level_iters))
-    per_px = {"k_update<false>": 30, "k_update<true>": 41, "k_merge_depth_off": 48, "k_compute_normal": 24,
-              "k_raster_draw": 28, "k_raster_resolve": 72, "k_read_frame": 44, "k_transform_vertex_map": 28,
-              "k_project_mask": 14, "k_segment_pass": 26, "k_vertex_map_gl": 16, "k_vertex_map_kinect": 14,
-              "k_cpy_char3": 15, "k_intensity_sobel": 20}
-    return per_px[kernel] * P
+    return PER_PX[kernel] * P
+
+
+# per pixel, fused frame kernels: inputs read once + outputs written once
+PER_PX = {"k_frame_preprocess": 2 + 3 + 12 + 12 + 12 + 4 + 4,          # depth u16, BGR8 -> VMap, NMap, RGB, Gx, Gy
+          "k_predict_draw": 12,                                        # VMap in (z-buffer atomics not counted)
+          "k_predict_resolve": 8 + 12 + 16 + 1 + 1 + 12 + 16 + 1 + 1,  # zbuf, VMap/RGBD/Mask/Label in -> out
+          "k_normal_segment": 12 + 12 + 1 + 1,                         # VMap -> NMap, Label in/out
+          "k_segment_pass_pb": 12 + 12 + 1 + 1,
+          "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12,         # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap
+          "k_update<false>": 12 + 1 + 1 + 8, "k_update<true>": 12 + 16 + 1 + 1 + 10}
+
+
+def hbm_bound_kernels(pkg, lib, synth, torch, device):
+    """Fusion / raycast kernels at the sizes where they ARE bandwidth-bound (BASELINE configs[2], [3]):
+    the Bump decode of a 256-plane x 512x512 model in one launch, and the fused frame kernels at
+    1920x1080.  HIP events around every launch (library hook), algorithmic bytes from DESIGN.md."""
+    out = []
+
+    def measure(ctx_h, kernel, run, launches_expected=None):
+        lib.rgbdslam_profile_kernel(ctx_h, kernel.encode())
+        run()
+        tot, cnt = C.c_double(), C.c_int()
+        lib.rgbdslam_profile_read(ctx_h, C.byref(tot), C.byref(cnt))
+        lib.rgbdslam_profile_kernel(ctx_h, None)
+        return tot.value, cnt.value
+
+    # ---- config 3: decode (VertexFromBump, 54 B per cell) of 256 planes x 512 x 512 ----
+    planes, N = 256, 512
+    ctx = pkg.Context(device)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    bump = torch.randint(0, 32767, (planes, N, N, 3), dtype=torch.int16, device="cuda", generator=g)
+    rgbb = torch.randint(0, 255, (planes, N, N, 3), dtype=torch.uint8, device="cuda", generator=g)
+    mask = torch.randint(11, 60, (planes, N, N), dtype=torch.uint8, device="cuda", generator=g)
+    param = torch.tensor([0.0, 0.0, 1.0, -2.0, 500.0, 500.0, -1.0, -1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0], device="cuda").repeat(planes, 1)
+    vout = torch.empty(planes, N, N, 3, device="cuda"); cout = torch.empty(planes, N, N, 4, device="cuda"); kout = torch.empty(planes, N, N, 4, device="cuda")
+    tab = lambda t: torch.tensor([t[k].data_ptr() for k in range(planes)], dtype=torch.int64, device="cuda")
+    tabs = [tab(x) for x in (vout, cout, kout, bump, rgbb, mask, param)]
+    reps = 6
+
+    def run_decode():
+        for _ in range(reps):
+            ctx.vertex_from_bump_batch(*tabs, 0, planes, N, N)
+        ctx.synchronize()
+    run_decode()
+    tot, cnt = measure(ctx._h, "k_vertex_from_bump_batch", run_decode)
+    nbytes = 54 * planes * N * N
+    gbs = nbytes * cnt / (tot * 1e-3) / 1e9
+    out.append({"kernel": "k_vertex_from_bump_batch", "workload": "decode of 256 planes x 512x512 Bump cells, one launch",
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1),
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    del bump, rgbb, mask, vout, cout, kout, tabs
+    ctx.close()
+    torch.cuda.empty_cache()
+
+    # ---- config 4 size: the fused frame kernels at 1920x1080 ----
+    n, m = 1080, 1920
+    calib = synth.calib_for(n, m)
+    pool = synth.sequence(4, n, m, calib, noise_sigma=0.001)
+    dd = [torch.from_numpy(p[0]).cuda() for p in pool]
+    bb = [torch.from_numpy(p[1]).cuda() for p in pool]
+    rg = pkg.RG(n, m, calib, device=device)
+    host = pkg.load_host()
+    host.slamhost_rg_ctx.restype = C.c_void_p
+    ch = C.c_void_p(host.slamhost_rg_ctx(rg._h))
+    eq, centers = synth.plane_equations()
+    rg.run_device_sequence(dd[:1], bb[:1])
+    rg.set_planes(eq, centers)
+    order = [1, 2, 3, 2, 1, 0, 1, 2]
+    run_seq = lambda: rg.run_device_sequence([dd[i] for i in order], [bb[i] for i in order])
+    run_seq()
+    for kernel in ("k_model_merge", "k_predict_resolve", "k_frame_preprocess", "k_predict_draw", "k_update<true>"):
+        tot, cnt = measure(ch, kernel, run_seq)
+        nbytes = PER_PX[kernel] * n * m
+        gbs = nbytes * cnt / (tot * 1e-3) / 1e9
+        out.append({"kernel": kernel, "workload": "fused frame pipeline at 1920x1080", "algorithmic_bytes_per_launch": nbytes,
+                    "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1), "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    rg.close()
+    return out
 
 
 def main():
@@ -56,6 +131,7 @@ def main():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--kernel", default="k_icp_iter", help="kernel whose roofline is reported")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-large-kernels", action="store_true", help="skip the config-3/config-4-size kernel rooflines")
     ap.add_argument("--profile-in-timed-region", action="store_true",
                     help="record the roofline events inside the timed region instead of in a second pass")
     args = ap.parse_args()
@@ -165,6 +241,13 @@ def main():
                "sample": "%d frames of the same %dx%d sequence, oracle display() loop (scalar C, -O2, 1 thread)"
                          % (args.cpu_frames, m, n)}
 
+    large = None
+    if rank == 0 and world == 1 and not args.no_large_kernels:
+        rg.close()
+        del depth_dev, bgr_dev
+        torch.cuda.empty_cache()
+        large = hbm_bound_kernels(pkg, lib, synth, torch, local)
+
     if rank == 0:
         out = {"metric": "ICP+fusion frames/sec at 640x480", "value": round(world * args.steps / dt, 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -173,7 +256,7 @@ def main():
                                       "(<= 3/4/5 iterations) + prediction + merge + Bump fusion into 3 planes of 1024x1024"
                                       % (m, n),
                           "sequences": world, "frames_resident_in_hbm": True},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "hbm_bound_kernels": large}
         print(json.dumps(out), flush=True)
     rg.close()
     if world > 1:

@@ -229,7 +229,7 @@ int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *RGBA, float
                               const uint16_t *Bump, const uint8_t *RGB_bump, const uint8_t *Mask,
                               const float *param_dev, int n, int m, int lvl);
 
-/* The same decode for planes [plane_lo, plane_hi) in ONE launch (lvl = 1, m % 4 == 0): the tables are
+/* The same decode for planes [plane_lo, plane_hi) in ONE launch (lvl = 1): the tables are
  * device arrays of per-plane device pointers like Update_cu's; outputs one buffer per plane (the
  * reference keeps one VBO triple per Primitive, Primitive.h:60-66).  For models of hundreds of
  * planes (BASELINE configs[2]) where one launch per plane would be launch-bound. */

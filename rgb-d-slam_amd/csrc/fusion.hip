@@ -77,16 +77,16 @@ __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *
 
 // ---- D1/Primitive.cu:31-93 VertexFromBumpKernel ----------------------------------------------------
 struct BumpCell { float3 v; float4 c, k; };
+struct BumpParam { float p[14]; };
+// u8 / 255.0 (Primitive.cu:80-82,90): (float)((double)x / C) == x / (float)C for float x -- double
+// rounding is innocuous for division (53 >= 2*24 + 2)
+__device__ __forceinline__ float unorm8(uint8_t x) { return (float)x / 255.0f; }
+// UNORM = functor returning x/255 for a byte (direct division, or a 256-entry LDS table)
+template <typename UNORM>
 __device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16_t b2, uint8_t r, uint8_t g, uint8_t b, uint8_t mk,
-                                                const float *__restrict__ param, float fi, float fj) {
+                                                const BumpParam &P, float fi, float fj, UNORM unorm) {
+    const float *param = P.p;
     BumpCell o;
-    if (mk < 11 && mk != 1) {                                   // Primitive.cu:47
-        o.v.x = o.v.y = o.v.z = 0.0f;
-        o.c.x = o.c.y = o.c.z = o.c.w = 0.0f;
-        o.k = o.c;
-        return o;
-    }
-    // (float)((double)x / C) == x / (float)C for float x: double rounding is innocuous for division
     float s0 = (float)b0 / 60000.0f;
     float s1 = (float)b1 / 60000.0f;
     float x = (float)((double)(fi + s0) * 2.0 / (double)param[4] + (double)param[6]);
@@ -95,15 +95,26 @@ __device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16
     o.v.x = (x * param[8] + y * param[11]) + d * param[0];
     o.v.y = (x * param[9] + y * param[12]) + d * param[1];
     o.v.z = (x * param[10] + y * param[13]) + d * param[2];
-    o.c.x = (float)r / 255.0f;
-    o.c.y = (float)g / 255.0f;
-    o.c.z = (float)b / 255.0f;
+    o.c.x = unorm(r);
+    o.c.y = unorm(g);
+    o.c.z = unorm(b);
     o.c.w = 1.0f;
     o.k.x = (float)((10.0 + (double)o.v.x) / 20.0);
     o.k.y = (float)((10.0 + (double)o.v.y) / 20.0);
     o.k.z = (float)((10.0 + (double)o.v.z) / 20.0);
-    o.k.w = (float)mk / 255.0f;
+    o.k.w = unorm(mk);
+    if (mk < 11 && mk != 1) {                                   // Primitive.cu:47: empty cell -> zeros (branch-free select)
+        o.v.x = o.v.y = o.v.z = 0.0f;
+        o.c.x = o.c.y = o.c.z = o.c.w = 0.0f;
+        o.k = o.c;
+    }
     return o;
+}
+__device__ __forceinline__ BumpParam load_param(const float *__restrict__ param) {
+    BumpParam P;
+#pragma unroll
+    for (int k = 0; k < 14; k++) P.p[k] = param[k];
+    return P;
 }
 
 __global__ void k_vertex_from_bump(float *__restrict__ VMap, float *__restrict__ RGBA, float *__restrict__ MaskOut,
@@ -115,58 +126,65 @@ __global__ void k_vertex_from_bump(float *__restrict__ VMap, float *__restrict__
     size_t idx = (size_t)i * mo + j;
     size_t ref = (size_t)(lvl * i) * m + (size_t)(lvl * j);
     BumpCell o = decode_cell(Bump[3 * ref], Bump[3 * ref + 1], Bump[3 * ref + 2], RGB_bump[3 * ref], RGB_bump[3 * ref + 1],
-                             RGB_bump[3 * ref + 2], Mask[ref], param, (float)(lvl * i), (float)(lvl * j));
+                             RGB_bump[3 * ref + 2], Mask[ref], load_param(param), (float)(lvl * i), (float)(lvl * j), unorm8);
     st3(VMap, idx, o.v.x, o.v.y, o.v.z);
     *(float4 *)(RGBA + 4 * idx) = o.c;
     *(float4 *)(MaskOut + 4 * idx) = o.k;
 }
 
-// Whole-model decode in ONE launch (config 3: hundreds of planes): blockIdx.z = plane, each lane
-// decodes 4 consecutive cells of a row, so every access is an aligned dword vector -- 24 B of Bump,
-// 12 B of RGB, 4 B of Mask in; 48 + 64 + 64 B out -- and a wavefront streams contiguous memory.
-// Needs lvl == 1 and m % 4 == 0.
+// Whole-model decode in ONE launch (config 3: hundreds of planes): blockIdx.z = plane.  A wavefront
+// owns 256 consecutive cells; lane L decodes cells L, L+64, L+128, L+192 of them, so every store
+// instruction writes one contiguous run (768 B of VMap, 1 KB of RGBA / MaskOut) -- the outputs are
+// 82 % of the traffic.  x/255 comes from a 256-entry LDS table.  Needs lvl == 1.
 #define DEC_CELLS 4
 __global__ __launch_bounds__(256)
 void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *__restrict__ RGBATab,
                               float *const *__restrict__ MaskOutTab, const uint16_t *const *__restrict__ BumpTab,
                               const uint8_t *const *__restrict__ RGBTab, const uint8_t *const *__restrict__ MaskTab,
                               const float *const *__restrict__ ParamTab, int plane_lo, int n, int m) {
+    __shared__ float lut[256];                                  // x / 255 for every byte: one division per thread
+    lut[threadIdx.x] = unorm8((uint8_t)threadIdx.x);
+    __syncthreads();
     const int plane = plane_lo + blockIdx.z;
-    const size_t groups = (size_t)n * m / DEC_CELLS;
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= groups) return;
-    const float *__restrict__ param = ParamTab[plane];
-    const size_t cell0 = g * DEC_CELLS;
-    const int i = (int)(cell0 / m), j0 = (int)(cell0 % m);
-    const uint4 bq = *(const uint4 *)(BumpTab[plane] + 3 * cell0);            // 8 of the 12 u16
-    const uint2 bq2 = *(const uint2 *)(BumpTab[plane] + 3 * cell0 + 8);       // the other 4
-    const uint32_t bw[6] = {bq.x, bq.y, bq.z, bq.w, bq2.x, bq2.y};
-    const uint32_t *cp = (const uint32_t *)(RGBTab[plane] + 3 * cell0);
-    const uint32_t cw[3] = {cp[0], cp[1], cp[2]};
-    const uint32_t mw = *(const uint32_t *)(MaskTab[plane] + cell0);
-    float vo[12];
-    float4 co[4], ko[4];
+    const size_t cells = (size_t)n * m;
+    const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * DEC_CELLS) + (threadIdx.x & 63);
+    if (base >= cells) return;
+    const BumpParam P = load_param(ParamTab[plane]);
+    auto unorm = [&](uint8_t x) { return lut[x]; };
+    const uint16_t *__restrict__ Bump = BumpTab[plane];
+    const uint8_t *__restrict__ RGBb = RGBTab[plane];
+    const uint8_t *__restrict__ Maskb = MaskTab[plane];
+    float *__restrict__ VMap = VMapTab[plane];
+    float *__restrict__ RGBA = RGBATab[plane];
+    float *__restrict__ MaskOut = MaskOutTab[plane];
+    uint16_t b[DEC_CELLS][3];
+    uint8_t c[DEC_CELLS][3], mk[DEC_CELLS];
 #pragma unroll
-    for (int k = 0; k < DEC_CELLS; k++) {
-        // u16 #(3k+c) sits in word (3k+c)/2, half (3k+c)%2; byte #(3k+c) in word (3k+c)/4, byte (3k+c)%4
-        uint16_t b[3];
-        uint8_t c[3];
+    for (int k = 0; k < DEC_CELLS; k++) {                       // all loads first
+        size_t cell = base + 64 * k;
+        bool in = cell < cells;
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            int e = 3 * k + q;
-            b[q] = (uint16_t)(bw[e >> 1] >> (16 * (e & 1)));
-            c[q] = (uint8_t)(cw[e >> 2] >> (8 * (e & 3)));
+            b[k][q] = in ? Bump[3 * cell + q] : (uint16_t)0;
+            c[k][q] = in ? RGBb[3 * cell + q] : (uint8_t)0;
         }
-        BumpCell o = decode_cell(b[0], b[1], b[2], c[0], c[1], c[2], (uint8_t)(mw >> (8 * k)), param, (float)i, (float)(j0 + k));
-        vo[3 * k] = o.v.x; vo[3 * k + 1] = o.v.y; vo[3 * k + 2] = o.v.z;
-        co[k] = o.c; ko[k] = o.k;
+        mk[k] = in ? Maskb[cell] : (uint8_t)0;
     }
-    float4 *vp = (float4 *)(VMapTab[plane] + 3 * cell0);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { float4 t; t.x = vo[4 * k]; t.y = vo[4 * k + 1]; t.z = vo[4 * k + 2]; t.w = vo[4 * k + 3]; vp[k] = t; }
-    float4 *cpo = (float4 *)(RGBATab[plane] + 4 * cell0), *kpo = (float4 *)(MaskOutTab[plane] + 4 * cell0);
-#pragma unroll
-    for (int k = 0; k < DEC_CELLS; k++) { cpo[k] = co[k]; kpo[k] = ko[k]; }
+    for (int k = 0; k < DEC_CELLS; k++) {
+        size_t cell = base + 64 * k;
+        if (cell >= cells) break;
+        int i = (int)(cell / (size_t)m), j = (int)(cell % (size_t)m);
+        BumpCell o = decode_cell(b[k][0], b[k][1], b[k][2], c[k][0], c[k][1], c[k][2], mk[k], P, (float)i, (float)j, unorm);
+        // streaming outputs: written once, never re-read by this kernel
+        __builtin_nontemporal_store(o.v.x, VMap + 3 * cell);
+        __builtin_nontemporal_store(o.v.y, VMap + 3 * cell + 1);
+        __builtin_nontemporal_store(o.v.z, VMap + 3 * cell + 2);
+        typedef float vfloat4 __attribute__((ext_vector_type(4)));
+        vfloat4 cv = {o.c.x, o.c.y, o.c.z, o.c.w}, kv = {o.k.x, o.k.y, o.k.z, o.k.w};
+        __builtin_nontemporal_store(cv, (vfloat4 *)(RGBA + 4 * cell));
+        __builtin_nontemporal_store(kv, (vfloat4 *)(MaskOut + 4 * cell));
+    }
 }
 
 // =================================================================================================
@@ -224,10 +242,10 @@ extern "C" int rgbdslam_vertex_from_bump_batch(rgbdslam_ctx *ctx, float **VMapTa
                                                int plane_lo, int plane_hi, int n, int m) {
     if (!ctx || !VMapTab || !RGBATab || !MaskOutTab || !BumpTab || !RGBTab || !MaskTab || !ParamTab) return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || plane_lo < 0 || plane_hi < plane_lo) return RGBDSLAM_E_ARG;
-    if (m % DEC_CELLS != 0 || plane_hi - plane_lo > 65535) return RGBDSLAM_E_LIMIT;
+    if (plane_hi - plane_lo > 65535 || (size_t)n * m > 0x7FFFFFFFu) return RGBDSLAM_E_LIMIT;
     if (plane_hi == plane_lo) return 0;
-    size_t groups = (size_t)n * m / DEC_CELLS;
-    dim3 grid((unsigned)((groups + 255) / 256), 1, (unsigned)(plane_hi - plane_lo));
+    size_t cells = (size_t)n * m;
+    dim3 grid((unsigned)((cells + 256 * DEC_CELLS - 1) / (256 * DEC_CELLS)), 1, (unsigned)(plane_hi - plane_lo));
     KLAUNCH(ctx, k_vertex_from_bump_batch, grid, dim3(256), VMapTab, RGBATab, MaskOutTab, (const uint16_t *const *)BumpTab,
             (const uint8_t *const *)RGBTab, (const uint8_t *const *)MaskTab, (const float *const *)ParamTab, plane_lo, n, m);
     HIP_TRY(hipGetLastError());
