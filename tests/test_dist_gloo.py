@@ -1,0 +1,157 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the multi-GPU forms of the path:
+the partitioning / collective logic of rgb-d-slam_amd/multigpu.py with the CPU oracle standing in
+for the HIP kernels.  On the GPU box the same functions run over RCCL."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIN20 = float(np.sin(np.deg2rad(20.0)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _scene(n, m):
+    from oracle import oracle as orc
+    synth = importlib.import_module("rgb-d-slam_amd.synth")
+    calib = synth.calib_for(n, m)
+    d0, c0 = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    R1, t1 = synth.pair_offset_pose()
+    d1, c1 = synth.render(R1, t1, n, m, calib)
+    v0 = orc.vertex_map_kinect(d0, calib); n0 = orc.compute_normal(v0); rgb0 = orc.cpy_char3(c0)
+    v1 = orc.vertex_map_kinect(d1, calib); n1 = orc.compute_normal(v1); rgb1 = orc.cpy_char3(c1)
+    rgbd0 = orc.add_zbuff_off(d0, rgb0, calib)
+    _, gx, gy = orc.intensity_sobel(rgb1)
+    return orc, synth, calib, dict(v0=v0, n0=n0, rgbd0=rgbd0, v1=v1, n1=n1, rgb1=rgb1, gx=gx, gy=gy, d0=d0)
+
+
+# ---- row-sharded ICP: band sums -> all-gather -> rank-ordered total -> identical solve --------------
+def _sharded_icp(rank, world):
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m, fact = 120, 160, 1
+    orc, synth, calib, s = _scene(n, m)
+    I, z = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)
+    gr, gc = orc.icp_grid(n, m, fact)
+    buf, _ = orc.icp_match(calib[:4], I, z, s["v1"], s["n1"], s["rgb1"], s["gx"], s["gy"], s["v0"], s["n0"], s["rgbd0"], 0.05, SIN20, fact)
+    lo, hi = mg.band_rows(rank, world, gr)
+    local = np.ascontiguousarray(buf.reshape(27, gc, gr)[:, :, lo:hi]).reshape(27, -1)   # band-local blk = brow + bcol*rows
+    sums = orc.icp_reduce(local)
+    gathered = mg.allgather_sums(torch.from_numpy(sums))
+    total = mg.ordered_total(gathered).numpy()
+    A = np.zeros((6, 6), np.float32); b = np.zeros(6, np.float32)
+    k = 0
+    for i in range(6):
+        for j in range(i, 7):
+            if j == 6: b[i] = total[k]
+            else: A[i, j] = A[j, i] = total[k]
+            k += 1
+    rc, x = orc.llt_solve6(A, b)
+    full = orc.icp_reduce(buf)
+    return dict(band=(lo, hi), total=total.tobytes(), x=x.tobytes(), rc=rc, full=full, total_f=total, gathered=gathered.numpy())
+
+
+def test_row_sharded_icp_allgather_two_ranks():
+    out = _spawn(_sharded_icp)
+    assert out[0]["band"][1] == out[1]["band"][0] and out[0]["band"][0] == 0       # bands tile the block rows
+    assert out[0]["total"] == out[1]["total"] and out[0]["x"] == out[1]["x"]        # bit-identical on every rank
+    assert out[0]["rc"] == 0
+    assert np.array_equal(out[0]["gathered"], out[1]["gathered"])
+    # the sharded total differs from the single-GPU two-stage sum only by float32 summation order
+    assert np.allclose(out[0]["total_f"], out[0]["full"], rtol=2e-5, atol=1e-6)
+    assert np.abs(out[0]["full"]).max() > 1.0
+
+
+# ---- plane-partitioned fusion: disjoint plane ranges, union == single-process result ------------------
+def _plane_fusion(rank, world):
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m, n_prim, nb = 60, 80, 128, 3
+    orc, synth, calib, s = _scene(n, m)
+    eq, centers = synth.plane_equations()
+    pose = np.eye(4, dtype=np.float32).T.reshape(-1)
+    label = orc.seed_labels(s["v0"], s["n0"], pose, eq)
+    mask = orc.init_mask(s["rgbd0"])
+    params = []
+    for k in range(nb):
+        p = np.zeros(14, np.float32)
+        p[0:3], p[3], p[4:6] = eq[k, 0:3], eq[k, 9], 500.0
+        p[6] = centers[k] @ eq[k, 3:6] - n_prim * 0.004 / 2
+        p[7] = centers[k] @ eq[k, 6:9] - n_prim * 0.004 / 2
+        p[8:11], p[11:14] = eq[k, 3:6], eq[k, 6:9]
+        params.append(p)
+    bumps = [np.zeros((n_prim, n_prim, 3), np.uint16) for _ in range(nb)]
+    rgbs = [np.zeros((n_prim, n_prim, 3), np.uint8) for _ in range(nb)]
+    masks = [np.zeros((n_prim, n_prim), np.uint8) for _ in range(nb)]
+    claims = [np.zeros((n_prim, n_prim), np.uint64) for _ in range(nb)]
+    lo, hi = mg.plane_range(rank, world, nb)
+    orc.update(bumps, rgbs, masks, params, claims, 1, s["v0"], s["rgbd0"], mask, label, pose, lo, hi)
+    # owner gathers: every rank contributes only its planes; others stay untouched (zeros)
+    mine = torch.from_numpy(np.stack(masks).astype(np.int32))
+    dist.all_reduce(mine, op=dist.ReduceOp.SUM)                   # disjoint support -> the sum is the union
+    untouched = all(not masks[k].any() for k in range(nb) if not (lo <= k < hi))
+    ref_m = [np.zeros((n_prim, n_prim), np.uint8) for _ in range(nb)]
+    ref = ([np.zeros((n_prim, n_prim, 3), np.uint16) for _ in range(nb)], [np.zeros((n_prim, n_prim, 3), np.uint8) for _ in range(nb)],
+           ref_m, params, [np.zeros((n_prim, n_prim), np.uint64) for _ in range(nb)])
+    orc.update(*ref, 1, s["v0"], s["rgbd0"], mask, label, pose)
+    return dict(range=(lo, hi), untouched=untouched, union_ok=bool(np.array_equal(mine.numpy(), np.stack(ref_m).astype(np.int32))),
+                filled=int((np.stack(ref_m) > 10).sum()))
+
+
+def test_plane_partitioned_fusion_two_ranks():
+    out = _spawn(_plane_fusion)
+    assert out[0]["range"] == (0, 2) and out[1]["range"] == (2, 3)
+    assert all(o["untouched"] and o["union_ok"] for o in out)
+    assert out[0]["filled"] > 200
+
+
+# ---- bench aggregation (independent sequences, configs[4]) --------------------------------------------
+def _aggregate(rank, world):
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    return mg.aggregate_throughput(1.0 + rank, 100 + rank)
+
+
+def test_aggregate_throughput_max_time_total_units():
+    out = _spawn(_aggregate)
+    assert out[0] == out[1] == (201, 2.0)
+
+
+def test_partitions_cover_everything():
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    for nb, world in ((256, 8), (3, 2), (5, 8), (135, 4), (60, 7)):
+        spans = [mg.plane_range(r, world, nb) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == nb
+        assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
