@@ -491,3 +491,46 @@ def test_argument_errors(ctx, pkg):
     assert lib.rgbdslam_compute_normal(ctx._h, None, None, 480, 640, 1) == 1
     assert lib.rgbdslam_vertex_map_gl(ctx._h, None, None, 0, 0) == 1
     assert lib.rgbdslam_create(None, 0, None) == 1
+
+
+def test_sharded_aligner_over_rccl_single_rank(pkg, orc, pair):
+    """ShardedAligner (row-sharded ICP driver) over a real RCCL process group of world size 1: with one
+    band and one gathered part the result must be bit-identical to the single-GPU loop."""
+    import importlib
+    import os
+    import socket
+    import torch.distributed as dist
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    started = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        started = True
+    try:
+        n, m = 480, 640
+        calib = pair["calib"]
+        c2 = pkg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        c2.set_calibration_matrix(calib)
+        c2.alloc_buffers(60, 80)
+        g = {k: dev(pair[k]) for k in ("v0", "n0", "rgbd0", "v1", "n1", "rgb1", "gx1", "gy1")}
+        I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+        state = dev(np.concatenate([I, z, I, z]).astype(np.float32)); status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        al = mg.ShardedAligner(c2, pkg.icp_params(), n, m)
+        assert al.world == 1 and al.rank == 0
+        al.align(g["v1"], g["n1"], g["rgb1"], g["gx1"], g["gy1"], g["v0"], g["n0"], g["rgbd0"], state, status)
+        torch.cuda.synchronize()
+        ok, R, t, _ = orc.align_gauss_newton(orc.icp_params(), calib[:4], pair["v1"], pair["n1"], pair["rgb1"], pair["v0"], pair["n0"],
+                                             pair["rgbd0"], I, z, I, z)
+        sres = host(state)
+        assert ok and int(status[0]) == 1
+        same(sres[:9], R)
+        same(sres[9:12], t)
+        # the collective helper itself on the GPU backend
+        gathered = mg.allgather_sums(torch.arange(27, dtype=torch.float32, device="cuda"))
+        assert gathered.shape == (1, 27) and float(mg.ordered_total(gathered)[26]) == 26.0
+        c2.close()
+    finally:
+        if started:
+            dist.destroy_process_group()
