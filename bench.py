@@ -220,8 +220,19 @@ def main():
     bytes_per_frame = algo_bytes(args.kernel, n, m, level_iters)
     avg_ms = tot_ms.value / max(1, launches.value)
     achieved = bytes_per_frame * args.steps / (tot_ms.value * 1e-3) / 1e9 if tot_ms.value > 0 else 0.0
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of
+    # their own, profiles/*_pmc_traffic.json): counters cannot be read from inside this process
+    traffic = None
+    try:
+        import glob
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
+        t = pmc["bytes_per_launch"][args.kernel]
+        traffic = t["fetch"] + t["write"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": args.kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(bytes_per_frame / max(1.0, per_frame_launches)),
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_frame": round(per_frame_launches, 2),
                 "algorithmic_bytes_per_frame": bytes_per_frame, "icp_iterations_per_level": level_iters}
 
