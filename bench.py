@@ -143,10 +143,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # rehearsal on a 1-GPU box: RGBDSLAM_BENCH_BACKEND=gloo RGBDSLAM_BENCH_DEVICE=0 lets N ranks share one card
+    backend = os.environ.get("RGBDSLAM_BENCH_BACKEND", "nccl")
+    if "RGBDSLAM_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["RGBDSLAM_BENCH_DEVICE"])
     torch.cuda.set_device(local)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("rgb-d-slam_amd")
     synth = importlib.import_module("rgb-d-slam_amd.synth")
@@ -197,10 +205,10 @@ def main():
     dt = time.perf_counter() - t0
     pos += args.steps
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tr = torch.tensor([tracked], dtype=torch.int64, device="cuda")
+        tr = torch.tensor([tracked], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tr, op=dist.ReduceOp.MIN)
         tracked = int(tr.item())
     if tracked != args.steps:
