@@ -290,6 +290,22 @@ class RG:
                                                        C.byref(ok)), "run_device_sequence")
         return ok.value
 
+    def open_dataset(self, path, size_data=0, real=False, rgbd_rep=True):
+        """Dataset part of the reference constructor (D1/RG.h:145-156); returns the sequence length."""
+        size = C.c_int()
+        _hchk(self.lib.slamhost_rg_open_dataset(self._h, os.fsencode(path), int(size_data), int(real), int(rgbd_rep), C.byref(size)),
+              "open_dataset")
+        return size.value
+
+    def load_next_frame(self):
+        """RG::LoadFrame() (D1/RG.cpp:78-147): reads the next image pair from the dataset; False when exhausted."""
+        ok = C.c_int()
+        _hchk(self.lib.slamhost_rg_load_next_frame(self._h, C.byref(ok)), "load_next_frame")
+        return bool(ok.value)
+
+    def save_trajectory(self, filename):
+        _hchk(self.lib.slamhost_rg_save_trajectory(self._h, os.fsencode(filename)), "save_trajectory")
+
     def synchronize(self):
         _hchk(self.lib.slamhost_rg_synchronize(self._h), "synchronize")
 
@@ -324,3 +340,65 @@ class RG:
         if name.startswith("RGBb"):
             return out.reshape(self.N_prim, self.M_prim, 3)
         return out.reshape(self.N_prim, self.M_prim)
+
+
+# ---- dataset I/O and trajectory (host code, no GPU needed) --------------------------------
+def _pairs(buf):
+    return [tuple(l.split("\t")) for l in buf.value.decode().split("\n") if l]
+
+
+def load_timestamps(path, associated=False, cap=1 << 24):
+    """LoadTimeStamps / LoadAssociatedTimeStamps (D1/Utilities.cpp:171-304) -> [(depth_name, color_name), ...]."""
+    buf = C.create_string_buffer(cap)
+    cnt = C.c_int()
+    _hchk(load_host().slamhost_load_timestamps(os.fsencode(path), int(associated), buf, C.c_size_t(cap), C.byref(cnt)), "load_timestamps")
+    return _pairs(buf)
+
+
+def dataset_frame_files(path, count, size_data=0, real=False, rgbd_rep=True):
+    """File names RG::LoadFrame builds for its counter value `count` (D1/RG.cpp:105-139) + sequence length."""
+    buf = C.create_string_buffer(1 << 16)
+    size = C.c_int()
+    _hchk(load_host().slamhost_dataset_frame_files(os.fsencode(path), int(size_data), int(real), int(rgbd_rep), int(count), buf,
+                                                   C.c_size_t(1 << 16), C.byref(size)), "dataset_frame_files")
+    return _pairs(buf)[0], size.value
+
+
+def read_image(filename):
+    """cv::imread(file, CV_LOAD_IMAGE_UNCHANGED) for PNG / TIFF -> numpy [rows, cols(, channels)] u8/u16, BGR order."""
+    import numpy as np
+    r, c, ch, bits = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    h = load_host()
+    _hchk(h.slamhost_read_image(os.fsencode(filename), C.byref(r), C.byref(c), C.byref(ch), C.byref(bits), None, C.c_size_t(0)), "read_image")
+    out = np.empty((r.value, c.value, ch.value), np.uint16 if bits.value == 16 else np.uint8)
+    _hchk(h.slamhost_read_image(os.fsencode(filename), C.byref(r), C.byref(c), C.byref(ch), C.byref(bits), C.c_void_p(out.ctypes.data),
+                                C.c_size_t(out.nbytes)), "read_image")
+    return out[:, :, 0] if ch.value == 1 else out
+
+
+def write_image(filename, arr):
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    if a.dtype not in (np.uint8, np.uint16) or a.ndim not in (2, 3):
+        raise ValueError("write_image: u8/u16 arrays of 2 or 3 dimensions")
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    _hchk(load_host().slamhost_write_image(os.fsencode(filename), a.shape[0], a.shape[1], ch, 8 * a.itemsize, C.c_void_p(a.ctypes.data)),
+          "write_image")
+
+
+def matrix2quaternion(R):
+    """D1/Utilities.cpp:11-68; R = 3x3 (row, col) -> (w, x, y, z) float32."""
+    import numpy as np
+    Rc = np.ascontiguousarray(np.asarray(R, np.float32).T)     # column-major like Eigen
+    q = np.empty(4, np.float32)
+    load_host().slamhost_matrix2quaternion(C.c_void_p(Rc.ctypes.data), C.c_void_p(q.ctypes.data))
+    return q
+
+
+def save_trajectory(filename, Rs, ts, names):
+    """SaveTrajectory (D1/Utilities.cpp:500-546); Rs [k,3,3] (row, col), ts [k,3], names = listing entries."""
+    import numpy as np
+    Rc = np.ascontiguousarray(np.asarray(Rs, np.float32).transpose(0, 2, 1))
+    tc = np.ascontiguousarray(np.asarray(ts, np.float32))
+    _hchk(load_host().slamhost_save_trajectory(os.fsencode(filename), C.c_void_p(Rc.ctypes.data), C.c_void_p(tc.ctypes.data),
+                                               "\n".join(names).encode(), len(names)), "save_trajectory")

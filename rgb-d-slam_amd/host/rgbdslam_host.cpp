@@ -191,6 +191,22 @@ void OffLineFrame::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host
     preprocess(_color_dev_test.p, 3 * (size_t)_m);
 }
 
+void OffLineFrame::LoadFrame(const std::string &filename_depth, const std::string &filename_color) {
+    auto ends_with = [](const std::string &a, const char *suf) { size_t k = strlen(suf); return a.size() >= k && !a.compare(a.size() - k, k, suf); };
+    auto read = [&](const std::string &f) {
+        if (ends_with(f, ".png") || ends_with(f, ".PNG")) return read_png(f);
+        if (ends_with(f, ".tif") || ends_with(f, ".tiff")) return read_tiff(f);
+        throw Error("unsupported image container: " + f, RGBDSLAM_E_ARG);
+    };
+    Image depth_test = read(filename_depth);                                        // cv::imread(..., UNCHANGED), Frame.cpp:48
+    if (depth_test.rows != _n || depth_test.cols != _m || depth_test.channels != 1 || depth_test.bits != 16)
+        throw Error("depth image is not " + std::to_string(_m) + "x" + std::to_string(_n) + " 16UC1: " + filename_depth, RGBDSLAM_E_ARG);
+    Image color_test = read(filename_color);                                        // Frame.cpp:58
+    if (color_test.rows != _n || color_test.cols != _m || color_test.channels != 3 || color_test.bits != 8)
+        throw Error("colour image is not " + std::to_string(_m) + "x" + std::to_string(_n) + " 8UC3: " + filename_color, RGBDSLAM_E_ARG);
+    LoadFrame((const uint16_t *)depth_test.data.data(), color_test.data.data());
+}
+
 void OffLineFrame::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
     _depth_cur = depth_dev;
     _depth_pitch = depth_pitch;
@@ -434,6 +450,7 @@ RG::RG(int device, void *stream, int n, int m, const float *Calib, int lvl, floa
 
 RG::~RG() {
     if (_ctx) (void)rgbdslam_synchronize(_ctx);
+    delete _dataset;
     delete _graph;
     delete _predicted_frame;
     delete _frame;
@@ -456,6 +473,55 @@ bool RG::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const ui
     _frame->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
     _count++;
     return true;
+}
+
+void RG::OpenDataset(const char *path, int Sizedata, bool real, bool RGBDRep) {
+    if (_count != 1) throw Error("OpenDataset: frames were already loaded", RGBDSLAM_E_STATE);
+    delete _dataset;
+    _dataset = new Dataset(path, Sizedata, real, RGBDRep);
+    _first_out = true;
+}
+
+bool RG::LoadFrame() {
+    if (!_dataset) throw Error("LoadFrame(): no dataset opened", RGBDSLAM_E_STATE);
+    if (_count > _dataset->size() - 1) {                                            // RG.cpp:81-90 (Finish() belongs to N1/N2)
+        if (_first_out) {
+            memset(_poseRPrev.a, 0, sizeof(_poseRPrev.a));
+            _posetPrev = Vec3::Zero();
+        }
+        _first_out = false;
+        return false;
+    }
+    std::string filename_depth, filename_color;
+    _dataset->frame_files(_count, &filename_depth, &filename_color);                // RG.cpp:105-139
+    _frame->LoadFrame(filename_depth, filename_color);                              // RG.cpp:141
+    _traj_count.push_back(_count);
+    _count++;                                                                       // RG.cpp:144
+    return true;
+}
+
+void RG::SaveTrajectory(const char *filename) {
+    if (!_dataset || !_dataset->_RGBDRep || _dataset->_real)
+        throw Error("SaveTrajectory: needs a TUM listing (the stamp is cut out of its file names)", RGBDSLAM_E_STATE);
+    std::vector<Mat3> Rs;
+    std::vector<Vec3> ts;
+    std::vector<std::string> stamps;
+    if (fused) {
+        Sync();
+        if (frames_done > HISTORY_CAP) throw Error("SaveTrajectory: sequence longer than the pose history", RGBDSLAM_E_LIMIT);
+        for (int f = 0; f < frames_done; f++) {
+            const float *h = history_host(f);
+            Mat3 R; Vec3 t;
+            memcpy(R.a, h, 36); memcpy(t.v, h + 9, 12);
+            if (h[12] == 0.0f) t(0) = 100.0f;                                       // lost frame: the marker SaveTrajectory skips
+            Rs.push_back(R); ts.push_back(t);
+        }
+    } else {
+        Rs = _traj_R; ts = _traj_t;
+    }
+    if (_traj_count.size() < Rs.size()) throw Error("SaveTrajectory: frames were not loaded through LoadFrame()", RGBDSLAM_E_STATE);
+    for (size_t f = 0; f < Rs.size(); f++) stamps.push_back(_dataset->timestamp_depth(_traj_count[f]));
+    slam::SaveTrajectory(filename, Rs, ts, stamps);
 }
 
 bool RG::AlignFrameGaussNewton() {
@@ -653,8 +719,10 @@ int RG::Step() {
         _predicted_frame->InitMask();
         _poseRPrev = _poseR;
         _posetPrev = _poset;
+        if (_dataset) { Vec3 lost = _poset; lost(0) = 100.0f; _traj_R.push_back(_poseR); _traj_t.push_back(lost); }
         return 0;
     }
+    if (_dataset) { _traj_R.push_back(_poseR); _traj_t.push_back(_poset); }
     Mat3 poseRinv = _poseR.inverse();                                               // GP-demo.cpp:201-211
     Vec3 posetinv = poseRinv.neg() * _poset;
     Mat3 poseR = poseRinv * _poseRPrev;
@@ -793,6 +861,88 @@ int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {
     if (!rg || !R9_cm || !t3) return RGBDSLAM_E_ARG;
     memcpy(R9_cm, ((RG *)rg)->_poseR.a, 36);
     memcpy(t3, ((RG *)rg)->_poset.v, 12);
+    return 0;
+}
+// ---- dataset I/O ---------------------------------------------------------------------
+int slamhost_rg_open_dataset(void *rg, const char *path, int Sizedata, int real, int RGBDRep, int *size) {
+    if (!rg || !path) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->OpenDataset(path, Sizedata, real != 0, RGBDRep != 0));
+    if (size) *size = ((RG *)rg)->_dataset->size();
+    return 0;
+}
+int slamhost_rg_load_next_frame(void *rg, int *loaded) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    bool ok = false;
+    FACADE_TRY(ok = ((RG *)rg)->LoadFrame());
+    if (loaded) *loaded = ok ? 1 : 0;
+    return 0;
+}
+int slamhost_rg_save_trajectory(void *rg, const char *filename) {
+    if (!rg || !filename) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SaveTrajectory(filename));
+    return 0;
+}
+static int join_out(const std::vector<std::string> &a, const std::vector<std::string> &b, char *out, size_t cap, int *count) {
+    std::string s;
+    for (size_t k = 0; k < a.size(); k++) s += a[k] + "\t" + b[k] + "\n";
+    if (count) *count = (int)a.size();
+    if (s.size() + 1 > cap) return RGBDSLAM_E_LIMIT;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return 0;
+}
+// lines "depth_name\tcolor_name\n" of the associated pairs, in order
+int slamhost_load_timestamps(const char *path, int associated, char *out, size_t cap, int *count) {
+    if (!path || !out) return RGBDSLAM_E_ARG;
+    std::vector<std::string> d, c;
+    FACADE_TRY(if (associated) slam::LoadAssociatedTimeStamps(&d, &c, path); else slam::LoadTimeStamps(&d, &c, path));
+    return join_out(d, c, out, cap, count);
+}
+int slamhost_dataset_frame_files(const char *path, int Sizedata, int real, int RGBDRep, int count, char *out, size_t cap, int *size) {
+    if (!path || !out) return RGBDSLAM_E_ARG;
+    std::vector<std::string> d(1), c(1);
+    FACADE_TRY(slam::Dataset ds(path, Sizedata, real != 0, RGBDRep != 0); if (size) *size = ds.size(); ds.frame_files(count, &d[0], &c[0]));
+    return join_out(d, c, out, cap, nullptr);
+}
+int slamhost_read_image(const char *filename, int *rows, int *cols, int *channels, int *bits, void *buf, size_t cap) {
+    if (!filename || !rows || !cols || !channels || !bits) return RGBDSLAM_E_ARG;
+    slam::Image img;
+    std::string f(filename);
+    FACADE_TRY(img = (f.size() > 4 && f.substr(f.size() - 4) == ".png") ? slam::read_png(f) : slam::read_tiff(f));
+    *rows = img.rows; *cols = img.cols; *channels = img.channels; *bits = img.bits;
+    if (!buf) return 0;                                        // size query
+    if (img.data.size() > cap) return RGBDSLAM_E_LIMIT;
+    memcpy(buf, img.data.data(), img.data.size());
+    return 0;
+}
+int slamhost_write_image(const char *filename, int rows, int cols, int channels, int bits, const void *buf) {
+    if (!filename || !buf || rows <= 0 || cols <= 0) return RGBDSLAM_E_ARG;
+    slam::Image img;
+    img.rows = rows; img.cols = cols; img.channels = channels; img.bits = bits;
+    img.data.assign((const uint8_t *)buf, (const uint8_t *)buf + (size_t)rows * cols * channels * (bits / 8));
+    std::string f(filename);
+    FACADE_TRY(if (f.size() > 4 && f.substr(f.size() - 4) == ".png") slam::write_png(f, img); else slam::write_tiff(f, img));
+    return 0;
+}
+void slamhost_matrix2quaternion(const float *R_cm, float *q_wxyz) {
+    slam::Mat3 R; memcpy(R.a, R_cm, 36);
+    slam::matrix2quaternion(R, q_wxyz);
+}
+// names: `count` entries separated by '\n'
+int slamhost_save_trajectory(const char *filename, const float *R9_cm, const float *t3, const char *names, int count) {
+    if (!filename || !R9_cm || !t3 || !names || count < 0) return RGBDSLAM_E_ARG;
+    std::vector<slam::Mat3> Rs((size_t)count);
+    std::vector<slam::Vec3> ts((size_t)count);
+    std::vector<std::string> st;
+    for (int k = 0; k < count; k++) { memcpy(Rs[k].a, R9_cm + 9 * k, 36); memcpy(ts[k].v, t3 + 3 * k, 12); }
+    std::string all(names);
+    for (size_t pos = 0; st.size() < (size_t)count;) {
+        size_t nl = all.find('\n', pos);
+        st.push_back(all.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos));
+        if (nl == std::string::npos) break;
+        pos = nl + 1;
+    }
+    if (st.size() != (size_t)count) return RGBDSLAM_E_ARG;
+    FACADE_TRY(slam::SaveTrajectory(filename, Rs, ts, st));
     return 0;
 }
 // ---- host-logic test hooks (CPU only: no device work) ---------------------------------------------

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rgbdslam.h"
+#include "dataset_io.hpp"
 
 namespace slam {
 
@@ -89,6 +90,7 @@ public:
     // D1/Frame.cpp:43-77 with the cv::imread + GpuMat::upload pair replaced by the caller's
     // decoded images: host buffers (uploaded here) or device-resident ones (used in place).
     void LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);
+    void LoadFrame(const std::string &filename_depth, const std::string &filename_color);   // Frame.cpp:43-77 (image files)
     void LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
     // fused pipeline: when gradient buffers are attached, LoadFrame* runs rgbdslam_frame_preprocess
     // (one kernel for Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
@@ -187,6 +189,13 @@ public:
     ~RG();
     bool LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);   // RG.cpp:78-147 minus file I/O
     bool LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    // file sources: the dataset part of the constructor (RG.h:145-156), RG::LoadFrame() as in
+    // RG.cpp:78-147 (false once the sequence is exhausted), and the TUM trajectory of the frames processed so far
+    void OpenDataset(const char *path, int Sizedata, bool real = false, bool RGBDRep = true);
+    bool LoadFrame();
+    void SaveTrajectory(const char *filename);                     // Utilities.cpp:500-546 over the recorded poses
+    Dataset *_dataset = nullptr;
+    bool _first_out = true;
     bool AlignFrameGaussNewton();                                  // RG.cpp:797-932
     // plane injection: stands in for DetectPrimitives then runs CreatePrimitives
     void SetPlanes(const float *equations, const float *centers, int nbPlan);
@@ -228,6 +237,9 @@ private:
     DevBuf<float> _history_dev;
     float *_history_host = nullptr;
     int _history_synced = 0;
+    std::vector<int> _traj_count;                                  // dataset index of every processed frame
+    std::vector<Mat3> _traj_R;                                     // unfused path: poses pushed by Step()
+    std::vector<Vec3> _traj_t;
     rgbdslam_icp_params icp_params() const;
 };
 

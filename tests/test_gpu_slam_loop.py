@@ -181,3 +181,75 @@ def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth):
         same(rg.buffer(name), ref.buffer(name), name)
     rg.close()
     ref.close()
+
+
+@pytest.mark.parametrize("source", ["tum_fused", "tum_unfused", "numbered", "real_tiff"])
+def test_loop_from_dataset_files_and_trajectory(pkg, orc, synth, tmp_path, source):
+    """SURVEY 8f N3: RG::LoadFrame() from the three file sources of RG.cpp:105-139 (images written to disk,
+    decoded by the host library) gives the same poses as feeding the arrays, and SaveTrajectory writes the
+    text the oracle's restatement predicts from those poses.  The reference's frame counter starts at 1, so
+    the first listed frame is never loaded."""
+    import os
+    from oracle import dataset_io as ora
+    n, m, frames = 96, 128, 6
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(frames, n, m, calib)
+    d = str(tmp_path)
+    stamps = ["1305031102.%06d" % (160407 + 33333 * k) for k in range(frames)]
+    if source.startswith("tum"):
+        os.makedirs(d + "/depth"), os.makedirs(d + "/rgb")
+        with open(d + "/depth.txt", "w") as fd, open(d + "/rgb.txt", "w") as fc:
+            fd.write("# depth maps\n# file\n# timestamp filename\n")
+            fc.write("# color images\n# file\n# timestamp filename\n")
+            for k, (dep, col) in enumerate(seq):
+                pkg.write_image("%s/depth/%s.png" % (d, stamps[k]), dep)
+                pkg.write_image("%s/rgb/%s.png" % (d, stamps[k]), col)
+                fd.write("%s depth/%s.png\n" % (stamps[k], stamps[k]))
+                fc.write("%s rgb/%s.png\n" % (stamps[k], stamps[k]))
+            fc.write("1305031199.000000 rgb/none.png\n")   # unmatched tail entry: the one the iterator quirk skips
+        kw = dict()
+        expect = frames
+    elif source == "numbered":
+        os.makedirs(d + "/depth"), os.makedirs(d + "/color")
+        for k, (dep, col) in enumerate(seq):
+            pkg.write_image("%s/depth/%06d.png" % (d, k + 1), dep)
+            pkg.write_image("%s/color/%06d.png" % (d, k + 1), col)
+        kw = dict(size_data=frames, rgbd_rep=False)
+        expect = frames
+    else:
+        for k, (dep, col) in enumerate(seq):
+            pkg.write_image("%s/Depth_%d.tiff" % (d, k), dep)
+            pkg.write_image("%s/RGB_%d.tiff" % (d, k), col)
+        kw = dict(size_data=frames, real=True)
+        expect = frames
+    rg = pkg.RG(n, m, calib, N_prim=256, M_prim=256)
+    rg.set_fused(source != "tum_unfused")
+    assert rg.open_dataset(d, **kw) == expect
+    ref = orc.Slam(n, m, calib, N_prim=256, M_prim=256)
+    # the counter starts at 1: listing entry 1, file 000002.png (named count+1), Depth_1.tiff -- all frame 1 of `seq`
+    first = 1
+    Rs, ts, used = [], [], []
+    k = first
+    while rg.load_next_frame():
+        st = rg.step()
+        dep, col = seq[k]
+        assert st == ref.step(dep, col)
+        R, t = rg.pose()
+        Rr, tr = ref.pose()
+        same(np.array(R, np.float32), Rr, "frame %d poseR" % k)
+        same(np.array(t, np.float32), tr, "frame %d poset" % k)
+        Rs.append(np.array(R, np.float32).reshape(3, 3).T), ts.append(np.array(t, np.float32)), used.append(k)
+        k += 1
+    assert used == list(range(first, frames)) and not rg.load_next_frame()
+    if source.startswith("tum"):
+        out = d + "/trajectory.txt"
+        rg.save_trajectory(out)
+        names = ["depth/%s.png" % stamps[j] for j in used]
+        text = open(out).read()
+        assert text == ora.trajectory_text(Rs, ts, names)
+        assert len(text.strip().split("\n")) == 1 + len(used)
+    else:
+        with pytest.raises(pkg.SlamError):
+            rg.save_trajectory(d + "/trajectory.txt")
+    rg.close()
+    ref.close()
