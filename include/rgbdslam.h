@@ -222,6 +222,27 @@ int rgbdslam_update(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **RGBTab, uin
                     const float *VMap, const float *RGBD, const uint8_t *Mask,
                     const uint8_t *Label, const float *pose16_host, int N_prim, int M_prim,
                     int n, int m, int plane_lo, int plane_hi);
+/* Primitive.cuh:18  void QuadTrim(float *VMap, unsigned char *Mask, unsigned int *indices_dev,
+ *   unsigned short min_conf, unsigned int n, unsigned int m, float thresh, int lvl)
+ * Quad list of a plane mesh decoded at level lvl: 4 vertex ids per quad of the (n/lvl-1) x (m/lvl-1)
+ * grid, all 0 when the quad is dropped (a corner whose mask is neither 1 nor >= 10 + min_conf, or an
+ * edge/diagonal longer than thresh).  variant 0 = D1/Primitive.cu:95-152; variant 1 = the DemoStep2
+ * form (D2/Primitive.cu:367-424: corner rule mask < 11, ids emitted in the order 0,3,2,1). */
+int rgbdslam_quad_trim(rgbdslam_ctx *ctx, const float *VMap, const uint8_t *Mask,
+                       uint32_t *indices_dev, unsigned short min_conf, unsigned int n,
+                       unsigned int m, float thresh, int lvl, int variant);
+
+/* Whole-model mesh in ONE launch (lvl = 1), planes [plane_lo, plane_hi): VertexFromBump
+ * (Primitive.cuh:16) + ComputeNormal on the decoded vertices (D2/Primitive.cuh:22) + QuadTrim
+ * (Primitive.cuh:18), fused so that the Bump images are read once and the vertices never re-read.
+ * Tables are device arrays of per-plane device pointers as in Update_cu; NMapTab[k] holds 3*n*m
+ * floats, IndexTab[k] 4*(n-1)*(m-1) ids. */
+int rgbdslam_bump_mesh_batch(rgbdslam_ctx *ctx, float **VMapTab, float **RGBATab, float **MaskOutTab,
+                             float **NMapTab, uint32_t **IndexTab, uint16_t **BumpTab,
+                             uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, int plane_lo,
+                             int plane_hi, int n, int m, unsigned short min_conf, float thresh,
+                             int inverse_normals, int variant);
+
 /* Primitive.cuh:16  void VertexFromBump(float *VMap_VBO, float *RGB_VBO, float *Mask_VBO,
  *   unsigned short *Bump_dev, unsigned char *RGB_bump_dev, unsigned char *Mask_dev,
  *   float *param_dev, int n, int m, int lvl) */

@@ -215,6 +215,16 @@ def quad_trim_frame(vmap, thresh=0.1):
     return idx
 
 
+def quad_trim(vmap, mask, min_conf=0, thresh=0.1, lvl=1, variant=0, n=None, m=None):
+    """QuadTrim of a plane mesh; vmap holds the (n/lvl) x (m/lvl) decoded vertices, mask the plane's n x m bytes."""
+    if n is None:
+        n, m = mask.shape
+    idx = np.empty(((n // lvl - 1) * (m // lvl - 1), 4), np.uint32)
+    lib().orc_quad_trim(_p(idx), _p(_f32(vmap)), _p(np.ascontiguousarray(mask, np.uint8)), C.c_ushort(min_conf), C.c_uint(n), C.c_uint(m),
+                        C.c_float(thresh), int(lvl), int(variant))
+    return idx
+
+
 def raster(vmap, rgbd, calib, index=None, thresh=0.1, znear=0.5, zfar=10.0):
     n, m, _ = vmap.shape
     tex = np.empty((n, m, 4), np.float32)

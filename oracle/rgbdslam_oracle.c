@@ -767,6 +767,28 @@ void orc_quad_trim_frame(uint32_t *index, const float *VMap, int n, int m, float
         }
 }
 
+/* D1/Primitive.cu:95-147 (variant 0) and D2/Primitive.cu:367-419 (variant 1): quad list of a plane mesh.
+ * Vertex ids are formed as i*m/lvl + j in integer arithmetic and Mask is indexed with the same ids. */
+static int corner_rejected(uint8_t mk, int min_conf, int variant) {
+    return variant ? (mk < 11) : (mk != 1 && (int)mk - 10 < min_conf);
+}
+void orc_quad_trim(uint32_t *index, const float *VMap, const uint8_t *Mask, unsigned short min_conf,
+                   unsigned n, unsigned m, float thresh, int lvl, int variant) {
+    unsigned L = (unsigned)lvl;
+    for (unsigned i = 0; i + 2 <= n / L; i++)
+        for (unsigned j = 0; j + 2 <= m / L; j++) {
+            size_t q = (size_t)i * (m / L - 1) + j;
+            uint32_t id[4];
+            id[0] = i * m / L + j; id[1] = i * m / L + j + 1;
+            id[2] = (i + 1) * m / L + j + 1; id[3] = (i + 1) * m / L + j;
+            int cut = quad_trimmed(VMap, id, thresh);
+            for (int k = 0; k < 4; k++) cut |= corner_rejected(Mask[id[k]], (int)min_conf, variant);
+            if (cut) { index[4 * q] = index[4 * q + 1] = index[4 * q + 2] = index[4 * q + 3] = 0; }
+            else if (variant) { index[4 * q] = id[0]; index[4 * q + 1] = id[3]; index[4 * q + 2] = id[2]; index[4 * q + 3] = id[1]; }
+            else { index[4 * q] = id[0]; index[4 * q + 1] = id[1]; index[4 * q + 2] = id[2]; index[4 * q + 3] = id[3]; }
+        }
+}
+
 /* ---- compute rasteriser: fixed-point 1/256 px snapping, integer edge functions,
  *      top-left rule, perspective-correct interpolation in double, u64 min z-buffer ---------- */
 #define RASTER_MIN_DEPTH 1e-3f

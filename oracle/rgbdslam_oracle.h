@@ -112,6 +112,9 @@ void orc_vertex_from_bump(float *VMap, float *RGBA, float *MaskOut, const uint16
 /* D1/Kernel.cu:345-379 (TransformVertexMapKernel). */
 void orc_transform_vertex_map(const float *pose, float *VMap, float *RGBD, int n, int m);
 /* D1/Kernel.cu:381-438 (QuadTrimFrameKernel). */
+/* D1/Primitive.cu:95-152 (variant 0), D2/Primitive.cu:367-424 (variant 1) */
+void orc_quad_trim(uint32_t *index, const float *VMap, const uint8_t *Mask, unsigned short min_conf,
+                   unsigned n, unsigned m, float thresh, int lvl, int variant);
 void orc_quad_trim_frame(uint32_t *index, const float *VMap, int n, int m, float thresh);
 /* Software restatement of the GL_QUADS draw (D1/GP-demo.cpp:98-113, D1/Frame.cpp:247-279):
  * see DESIGN.md "compute rasteriser".  index may be NULL (quads trimmed inline with thresh).

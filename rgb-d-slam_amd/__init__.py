@@ -159,6 +159,17 @@ class Context:
              "vertex_from_bump_batch")
 
     # -- stage 5 --
+    def quad_trim(self, vmap, mask, indices, n, m, min_conf=0, thresh=0.1, lvl=1, variant=0):
+        _chk(self.lib.rgbdslam_quad_trim(self._h, _ptr(vmap), _ptr(mask), _ptr(indices), C.c_ushort(min_conf), C.c_uint(n), C.c_uint(m),
+                                         C.c_float(thresh), int(lvl), int(variant)), "quad_trim")
+
+    def bump_mesh_batch(self, vmap_tab, rgba_tab, mask_out_tab, nmap_tab, index_tab, bump_tab, rgb_tab, mask_tab, param_tab, plane_lo,
+                        plane_hi, n, m, min_conf=0, thresh=0.1, inverse_normals=False, variant=0):
+        _chk(self.lib.rgbdslam_bump_mesh_batch(self._h, _ptr(vmap_tab), _ptr(rgba_tab), _ptr(mask_out_tab), _ptr(nmap_tab),
+                                               _ptr(index_tab), _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab), _ptr(param_tab),
+                                               int(plane_lo), int(plane_hi), n, m, C.c_ushort(min_conf), C.c_float(thresh),
+                                               int(inverse_normals), int(variant)), "bump_mesh_batch")
+
     def transform_vertex_map(self, vmap, rgbd, n, m):
         _chk(self.lib.rgbdslam_transform_vertex_map(self._h, _ptr(vmap), _ptr(rgbd), n, m), "transform_vertex_map")
 

@@ -1,5 +1,6 @@
 // fusion.hip -- stage 4: multi-plane Bump-image fusion (scatter) and the Bump -> vertex decode.
 #include "common.hpp"
+#include "device_fns.hpp"
 
 // Winner rule replacing the data race of UpdateKernel (D1/Primitive.cu:309-349), see DESIGN.md:
 // all threads decide against the SNAPSHOT of the cell mask taken before any write; a gate-passing
@@ -76,47 +77,6 @@ __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *
 }
 
 // ---- D1/Primitive.cu:31-93 VertexFromBumpKernel ----------------------------------------------------
-struct BumpCell { float3 v; float4 c, k; };
-struct BumpParam { float p[14]; };
-// u8 / 255.0 (Primitive.cu:80-82,90): (float)((double)x / C) == x / (float)C for float x -- double
-// rounding is innocuous for division (53 >= 2*24 + 2)
-__device__ __forceinline__ float unorm8(uint8_t x) { return (float)x / 255.0f; }
-// UNORM = functor returning x/255 for a byte (direct division, or a 256-entry LDS table)
-template <typename UNORM>
-__device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16_t b2, uint8_t r, uint8_t g, uint8_t b, uint8_t mk,
-                                                const BumpParam &P, float fi, float fj, UNORM unorm) {
-    const float *param = P.p;
-    BumpCell o;
-    float s0 = (float)b0 / 60000.0f;
-    float s1 = (float)b1 / 60000.0f;
-    float x = (float)((double)(fi + s0) * 2.0 / (double)param[4] + (double)param[6]);
-    float y = (float)((double)(fj + s1) * 2.0 / (double)param[5] + (double)param[7]);
-    float d = (float)((double)param[3] + (((double)(float)b2 / 2000.0) - 15.0));
-    o.v.x = (x * param[8] + y * param[11]) + d * param[0];
-    o.v.y = (x * param[9] + y * param[12]) + d * param[1];
-    o.v.z = (x * param[10] + y * param[13]) + d * param[2];
-    o.c.x = unorm(r);
-    o.c.y = unorm(g);
-    o.c.z = unorm(b);
-    o.c.w = 1.0f;
-    o.k.x = (float)((10.0 + (double)o.v.x) / 20.0);
-    o.k.y = (float)((10.0 + (double)o.v.y) / 20.0);
-    o.k.z = (float)((10.0 + (double)o.v.z) / 20.0);
-    o.k.w = unorm(mk);
-    if (mk < 11 && mk != 1) {                                   // Primitive.cu:47: empty cell -> zeros (branch-free select)
-        o.v.x = o.v.y = o.v.z = 0.0f;
-        o.c.x = o.c.y = o.c.z = o.c.w = 0.0f;
-        o.k = o.c;
-    }
-    return o;
-}
-__device__ __forceinline__ BumpParam load_param(const float *__restrict__ param) {
-    BumpParam P;
-#pragma unroll
-    for (int k = 0; k < 14; k++) P.p[k] = param[k];
-    return P;
-}
-
 __global__ void k_vertex_from_bump(float *__restrict__ VMap, float *__restrict__ RGBA, float *__restrict__ MaskOut,
                                    const uint16_t *__restrict__ Bump, const uint8_t *__restrict__ RGB_bump,
                                    const uint8_t *__restrict__ Mask, const float *__restrict__ param, int n, int m, int lvl) {
