@@ -91,7 +91,23 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
     out.append({"kernel": "k_vertex_from_bump_batch", "workload": "decode of 256 planes x 512x512 Bump cells, one launch",
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1),
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
-    del bump, rgbb, mask, vout, cout, kout, tabs
+    # ---- the same model as a mesh (decode + normals + QuadTrim fused, 82 B per cell) ----
+    nout = torch.empty(planes, N, N, 3, device="cuda")
+    iout = torch.empty(planes, (N - 1) * (N - 1), 4, dtype=torch.int32, device="cuda")
+    mtabs = tabs[:3] + [tab(nout), tab(iout)] + tabs[3:]
+
+    def run_mesh():
+        for _ in range(reps):
+            ctx.bump_mesh_batch(*mtabs, 0, planes, N, N, 0, 0.1, False, 0)
+        ctx.synchronize()
+    run_mesh()
+    tot, cnt = measure(ctx._h, "k_bump_mesh", run_mesh)
+    nbytes = 82 * planes * N * N
+    gbs = nbytes * cnt / (tot * 1e-3) / 1e9
+    out.append({"kernel": "k_bump_mesh", "workload": "mesh (decode + normals + quad trim) of 256 planes x 512x512, one launch",
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1),
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    del bump, rgbb, mask, vout, cout, kout, nout, iout, tabs, mtabs
     ctx.close()
     torch.cuda.empty_cache()
 
