@@ -317,6 +317,10 @@ class RG:
     def save_trajectory(self, filename):
         _hchk(self.lib.slamhost_rg_save_trajectory(self._h, os.fsencode(filename)), "save_trajectory")
 
+    def save_model(self, directory, indx):
+        """Saving half of RG::Finish + SaveThread (D1/RG.cpp:16-59): cleaned planes + key frame in the reference's dump format."""
+        _hchk(self.lib.slamhost_rg_save_model(self._h, os.fsencode(directory), int(indx)), "save_model")
+
     def synchronize(self):
         _hchk(self.lib.slamhost_rg_synchronize(self._h), "synchronize")
 
@@ -413,3 +417,77 @@ def save_trajectory(filename, Rs, ts, names):
     tc = np.ascontiguousarray(np.asarray(ts, np.float32))
     _hchk(load_host().slamhost_save_trajectory(os.fsencode(filename), C.c_void_p(Rc.ctypes.data), C.c_void_p(tc.ctypes.data),
                                                "\n".join(names).encode(), len(names)), "save_trajectory")
+
+
+# ---- model dump format (host code) ----------------------------------------------------------
+def _eq19(p):
+    import numpy as np
+    return np.array(list(p["nmle"]) + [p["dist"]] + list(p["e1"]) + list(p["e2"]) + list(p["shift"]) + list(p["scale"]) +
+                    [p["size"][0], p["size"][1]] + list(p["anchor"]), np.float32)
+
+
+def _plane_dict(e):
+    return {"nmle": e[0:3].copy(), "dist": e[3], "e1": e[4:7].copy(), "e2": e[7:10].copy(), "shift": e[10:12].copy(),
+            "scale": e[12:14].copy(), "size": (int(e[14]), int(e[15])), "anchor": e[16:19].copy()}
+
+
+def save_graph(directory, indx, pose16, planes, clean=True):
+    """Primitive::Clean + Graph::save (D1/Primitive.cpp:4-134, D1/Graph.cpp:97-248).  planes: dicts with nmle, dist, e1,
+    e2, shift, scale, size, anchor and the arrays bump [n,m,3] u16, rgb [n,m,3] u8, mask [n,m] u8 (None = no data).
+    Returns the plane dicts as written (cleaned shift/size; size (0, 0) for dropped planes)."""
+    import numpy as np
+    nb = len(planes)
+    eq = np.zeros((max(nb, 1), 19), np.float32)
+    keep = []
+    B, R, M = (C.c_void_p * max(nb, 1))(), (C.c_void_p * max(nb, 1))(), (C.c_void_p * max(nb, 1))()
+    for k, p in enumerate(planes):
+        eq[k] = _eq19(p)
+        if p.get("bump") is None:
+            eq[k, 14:16] = 0
+            continue
+        arrs = (np.ascontiguousarray(p["bump"], np.uint16), np.ascontiguousarray(p["rgb"], np.uint8), np.ascontiguousarray(p["mask"], np.uint8))
+        keep.append(arrs)
+        B[k], R[k], M[k] = (a.ctypes.data for a in arrs)
+    _hchk(load_host().slamhost_save_graph(os.fsencode(directory), int(indx), _host16([float(v) for v in pose16]), nb,
+                                          C.c_void_p(eq.ctypes.data), B, R, M, int(clean)), "save_graph")
+    return [_plane_dict(eq[k]) for k in range(nb)]
+
+
+def save_frame(directory, indx, rgbd):
+    import numpy as np
+    a = np.ascontiguousarray(rgbd, np.float32)
+    _hchk(load_host().slamhost_save_frame(os.fsencode(directory), int(indx), C.c_void_p(a.ctypes.data), a.shape[0], a.shape[1]), "save_frame")
+
+
+def load_model(directory, indx):
+    """Model3D::Update's loader + KeyFrame (D2/Model3D.cpp:1050-1184, D2/KeyFrame.h:49-104).  None while the dump is
+    not complete; else dict(pose [16], planes [dicts incl. bump, rgb, mask(u16)], depth, rgb)."""
+    import numpy as np
+    h = load_host()
+    handle, ready = C.c_void_p(), C.c_int()
+    _hchk(h.slamhost_model_open(os.fsencode(directory), int(indx), C.byref(handle), C.byref(ready)), "model_open")
+    if not ready.value:
+        return None
+    try:
+        pose = np.empty(16, np.float32)
+        _hchk(h.slamhost_model_pose(handle, C.c_void_p(pose.ctypes.data)), "model_pose")
+        planes = []
+        for k in range(h.slamhost_model_count(handle)):
+            e = np.empty(19, np.float32)
+            _hchk(h.slamhost_model_plane(handle, k, C.c_void_p(e.ctypes.data)), "model_plane")
+            d = _plane_dict(e)
+            n, m = d["size"]
+            d["bump"], d["rgb"], d["mask"] = np.empty((n, m, 3), np.uint16), np.empty((n, m, 3), np.uint8), np.empty((n, m), np.uint16)
+            _hchk(h.slamhost_model_plane_data(handle, k, C.c_void_p(d["bump"].ctypes.data), C.c_void_p(d["rgb"].ctypes.data),
+                                              C.c_void_p(d["mask"].ctypes.data)), "model_plane_data")
+            planes.append(d)
+        imgs = []
+        for which, ch in ((0, 1), (1, 3)):
+            r, c = C.c_int(), C.c_int()
+            _hchk(h.slamhost_model_keyframe(handle, which, C.byref(r), C.byref(c), None), "model_keyframe")
+            a = np.empty((r.value, c.value, ch), np.uint16)
+            _hchk(h.slamhost_model_keyframe(handle, which, C.byref(r), C.byref(c), C.c_void_p(a.ctypes.data)), "model_keyframe")
+            imgs.append(a[:, :, 0] if ch == 1 else a)
+        return {"pose": pose, "planes": planes, "depth": imgs[0], "rgb": imgs[1]}
+    finally:
+        h.slamhost_model_close(handle)

@@ -524,6 +524,38 @@ void RG::SaveTrajectory(const char *filename) {
     slam::SaveTrajectory(filename, Rs, ts, stamps);
 }
 
+void RG::SaveModel(const char *dir, int indx) {
+    if (fused) Sync();
+    else check(rgbdslam_synchronize(_ctx), "synchronize");
+    const int N = _graph->_SizeVBUFF[0], M = _graph->_SizeVBUFF[1];
+    const size_t C = (size_t)N * M;
+    std::vector<PlanarPatch> nodes;
+    std::vector<uint8_t> mask8(C);
+    for (Primitive *Prim : _graph->_nodes) {                                        // RG.cpp:216-223 + Primitive.h:150-158
+        PlanarPatch P;
+        memcpy(P.nmle, Prim->_nmle, 12); memcpy(P.e1, Prim->_e1, 12); memcpy(P.e2, Prim->_e2, 12); memcpy(P.anchor, Prim->_anchor, 12);
+        P.dist = Prim->_dist;
+        memcpy(P.scale, Prim->_scale, 8); memcpy(P.Shift, Prim->_Shift, 8);
+        P.Size[0] = Prim->_Size[0]; P.Size[1] = Prim->_Size[1];
+        if (P.Size[0] != N || P.Size[1] != M) throw Error("SaveModel: plane size differs from the slab size", RGBDSLAM_E_STATE);
+        P.Bump.resize(3 * C); P.RGB.resize(3 * C); P.Mask.resize(C);
+        hip_check(hipMemcpy(P.Bump.data(), Prim->_Bump_dev, 6 * C, hipMemcpyDeviceToHost), "LoadOnCPU bump");
+        hip_check(hipMemcpy(P.RGB.data(), Prim->_RGB_dev, 3 * C, hipMemcpyDeviceToHost), "LoadOnCPU rgb");
+        hip_check(hipMemcpy(mask8.data(), Prim->_Mask_dev, C, hipMemcpyDeviceToHost), "LoadOnCPU mask");
+        for (size_t c = 0; c < C; c++) P.Mask[c] = mask8[c];
+        P.has_data = true;
+        nodes.push_back(std::move(P));
+    }
+    const int n = _frame->getN(), m = _frame->getM();
+    std::vector<float> rgbd((size_t)4 * n * m);                                     // RG.cpp:227
+    hip_check(hipMemcpy(rgbd.data(), _predicted_frame->getRGB(), rgbd.size() * sizeof(float), hipMemcpyDeviceToHost), "key frame download");
+    float pose[16];
+    pack_pose(_poseR, _poset, pose);                                                // RG.cpp:209-214
+    for (PlanarPatch &P : nodes) P.Clean();                                         // RG.cpp:27 (Graph::Clean)
+    SaveFrame(dir, indx + 1, rgbd.data(), n, m);                                    // RG.cpp:43
+    SaveGraph(dir, indx, pose, nodes);                                              // RG.cpp:44
+}
+
 bool RG::AlignFrameGaussNewton() {
     int n = _frame->getN(), m = _frame->getM();
     size_t pitch = 4 * (size_t)m;
@@ -943,6 +975,88 @@ int slamhost_save_trajectory(const char *filename, const float *R9_cm, const flo
     }
     if (st.size() != (size_t)count) return RGBDSLAM_E_ARG;
     FACADE_TRY(slam::SaveTrajectory(filename, Rs, ts, st));
+    return 0;
+}
+// ---- model dump format ---------------------------------------------------------------
+int slamhost_rg_save_model(void *rg, const char *dir, int indx) {
+    if (!rg || !dir) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SaveModel(dir, indx));
+    return 0;
+}
+// eq19 per plane: nmle(3) dist e1(3) e2(3) shift(2) scale(2) size(2) anchor(3); size 0 x 0 = plane without data
+static void patch_from(const float *e, slam::PlanarPatch *P) {
+    memcpy(P->nmle, e, 12); P->dist = e[3]; memcpy(P->e1, e + 4, 12); memcpy(P->e2, e + 7, 12); memcpy(P->Shift, e + 10, 8);
+    memcpy(P->scale, e + 12, 8); P->Size[0] = (int)e[14]; P->Size[1] = (int)e[15]; memcpy(P->anchor, e + 16, 12);
+}
+static void patch_to(const slam::PlanarPatch &P, float *e) {
+    memcpy(e, P.nmle, 12); e[3] = P.dist; memcpy(e + 4, P.e1, 12); memcpy(e + 7, P.e2, 12); memcpy(e + 10, P.Shift, 8);
+    memcpy(e + 12, P.scale, 8); e[14] = (float)P.Size[0]; e[15] = (float)P.Size[1]; memcpy(e + 16, P.anchor, 12);
+}
+// Clean (if `clean`) + Graph::save of host arrays; eq19 is updated in place with the cleaned shift/size
+int slamhost_save_graph(const char *dir, int indx, const float *pose16, int nb, float *eq19, const uint16_t *const *bumps,
+                        const uint8_t *const *rgbs, const uint8_t *const *masks, int clean) {
+    if (!dir || !pose16 || nb < 0 || (nb && (!eq19 || !bumps || !rgbs || !masks))) return RGBDSLAM_E_ARG;
+    std::vector<slam::PlanarPatch> nodes((size_t)nb);
+    for (int k = 0; k < nb; k++) {
+        slam::PlanarPatch &P = nodes[k];
+        patch_from(eq19 + 19 * k, &P);
+        size_t C = (size_t)P.Size[0] * P.Size[1];
+        if (!C || !bumps[k]) continue;
+        P.Bump.assign(bumps[k], bumps[k] + 3 * C); P.RGB.assign(rgbs[k], rgbs[k] + 3 * C); P.Mask.assign(masks[k], masks[k] + C);
+        P.has_data = true;
+        if (clean) P.Clean();
+    }
+    FACADE_TRY(slam::SaveGraph(dir, indx, pose16, nodes));
+    for (int k = 0; k < nb; k++) {
+        if (!nodes[k].has_data) { nodes[k].Size[0] = nodes[k].Size[1] = 0; }
+        patch_to(nodes[k], eq19 + 19 * k);
+    }
+    return 0;
+}
+int slamhost_save_frame(const char *dir, int indx, const float *rgbd, int n, int m) {
+    if (!dir || !rgbd || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    FACADE_TRY(slam::SaveFrame(dir, indx, rgbd, n, m));
+    return 0;
+}
+// reader: *ready = 0 while the dump's flag file is missing
+int slamhost_model_open(const char *dir, int indx, void **out, int *ready) {
+    if (!dir || !out || !ready) return RGBDSLAM_E_ARG;
+    slam::LoadedModel *M = new slam::LoadedModel();
+    bool ok = false;
+    try { ok = slam::LoadModel(dir, indx, M); }
+    catch (const std::exception &e) { delete M; g_last_error = e.what(); return RGBDSLAM_E_ARG; }
+    *ready = ok ? 1 : 0;
+    if (!ok) { delete M; M = nullptr; }
+    *out = M;
+    return 0;
+}
+int slamhost_model_close(void *h) { delete (slam::LoadedModel *)h; return 0; }
+int slamhost_model_count(void *h) { return h ? (int)((slam::LoadedModel *)h)->patches.size() : -1; }
+int slamhost_model_pose(void *h, float *pose16) {
+    if (!h || !pose16) return RGBDSLAM_E_ARG;
+    memcpy(pose16, ((slam::LoadedModel *)h)->pose, 64);
+    return 0;
+}
+int slamhost_model_plane(void *h, int k, float *eq19) {
+    slam::LoadedModel *M = (slam::LoadedModel *)h;
+    if (!M || !eq19 || k < 0 || k >= (int)M->patches.size()) return RGBDSLAM_E_ARG;
+    patch_to(M->patches[k], eq19);
+    return 0;
+}
+int slamhost_model_plane_data(void *h, int k, uint16_t *bump, uint8_t *rgb, uint16_t *mask) {
+    slam::LoadedModel *M = (slam::LoadedModel *)h;
+    if (!M || !bump || !rgb || !mask || k < 0 || k >= (int)M->patches.size()) return RGBDSLAM_E_ARG;
+    const slam::PlanarPatch &P = M->patches[k];
+    memcpy(bump, P.Bump.data(), P.Bump.size() * 2); memcpy(rgb, P.RGB.data(), P.RGB.size()); memcpy(mask, P.Mask.data(), P.Mask.size() * 2);
+    return 0;
+}
+// key-frame images: which = 0 depth (u16 [n,m]), 1 colour (u16 [n,m,3], B,G,R); buf = NULL queries the shape
+int slamhost_model_keyframe(void *h, int which, int *rows, int *cols, uint16_t *buf) {
+    slam::LoadedModel *M = (slam::LoadedModel *)h;
+    if (!M || !rows || !cols) return RGBDSLAM_E_ARG;
+    const slam::Image &I = which ? M->rgb : M->depth;
+    *rows = I.rows; *cols = I.cols;
+    if (buf) memcpy(buf, I.data.data(), I.data.size());
     return 0;
 }
 // ---- host-logic test hooks (CPU only: no device work) ---------------------------------------------

@@ -16,6 +16,7 @@
 
 #include "../../include/rgbdslam.h"
 #include "dataset_io.hpp"
+#include "model_io.hpp"
 
 namespace slam {
 
@@ -194,6 +195,9 @@ public:
     void OpenDataset(const char *path, int Sizedata, bool real = false, bool RGBDRep = true);
     bool LoadFrame();
     void SaveTrajectory(const char *filename);                     // Utilities.cpp:500-546 over the recorded poses
+    // model dump: the saving half of RG::Finish + SaveThread (RG.cpp:16-59,209-232) -- planes are
+    // copied to the host (Primitive::LoadOnCPU), cleaned, and written with the key frame; the live model is untouched
+    void SaveModel(const char *dir, int indx);
     Dataset *_dataset = nullptr;
     bool _first_out = true;
     bool AlignFrameGaussNewton();                                  // RG.cpp:797-932

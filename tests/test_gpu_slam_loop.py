@@ -253,3 +253,53 @@ def test_loop_from_dataset_files_and_trajectory(pkg, orc, synth, tmp_path, sourc
             rg.save_trajectory(d + "/trajectory.txt")
     rg.close()
     ref.close()
+
+
+def test_save_model_dump_round_trip(pkg, orc, synth, tmp_path):
+    """SURVEY 8f N2: RG::SaveModel (saving half of RG::Finish + SaveThread, RG.cpp:16-59) writes the fused
+    planes and the key frame in the reference's dump format; the DemoStep2-side loader reads back exactly the
+    cleaned Bump images the oracle's restatement derives from the device buffers."""
+    from oracle import model_io as ora
+    n, m, frames, N_prim = 120, 160, 5, 512
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(frames, n, m, calib)
+    eq, centers = synth.plane_equations()
+    rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    for f, (d, c) in enumerate(seq):
+        rg.load_frame(d, c)
+        assert rg.step() in (1, 2)
+        if f == 1:
+            rg.set_planes(eq, centers)
+    out = str(tmp_path)
+    rg.save_model(out, 0)
+    model = pkg.load_model(out, 0)
+    assert model is not None and len(model["planes"]) == 3
+    R, t = rg.pose()
+    pose = np.zeros(16, np.float32)
+    pose[[0, 1, 2, 4, 5, 6, 8, 9, 10]] = np.array(R, np.float32)
+    pose[12:15] = np.array(t, np.float32)
+    pose[15] = 1.0
+    assert open(out + "/Pose1.txt").read() == ora.pose_text(pose)
+    dimg, cimg = ora.frame_images(rg.buffer("RGBD"))
+    assert np.array_equal(model["depth"], dimg) and np.array_equal(model["rgb"], cimg)
+    assert (dimg > 0).mean() > 0.9
+    for k in range(3):
+        bump, rgbb, mask = rg.buffer("Bump%d" % k), rg.buffer("RGBb%d" % k), rg.buffer("Maskb%d" % k)
+        cb, cr, cm, sh = ora.clean(bump, rgbb, mask, (0.0, 0.0))
+        q = model["planes"][k]
+        assert q["size"] == cm.shape and cm.shape[0] < N_prim and (cm > 10).sum() > 100
+        same(q["bump"], cb, "Bump%d" % k)
+        same(q["rgb"], cr, "RGBb%d" % k)
+        same(q["mask"], cm.astype(np.uint16), "Maskb%d" % k)
+        # the cropped plane decodes to the same surface as the live one: the shift moved with the crop
+        ii, jj = np.nonzero(mask > 10)
+        i0, j0 = int(ii.min()), int(jj.min())
+        E = eq[k].astype(np.float32)
+        prm = lambda s0, s1: np.array([E[0], E[1], E[2], E[9], q["scale"][0], q["scale"][1], s0, s1, E[3], E[4], E[5], E[6], E[7], E[8]],
+                                      np.float32)
+        live_shift = q["shift"] - np.float32([i0 * 0.004, j0 * 0.004])
+        v_live, _, _ = orc.vertex_from_bump(bump, rgbb, mask, prm(*live_shift), 1)
+        v_crop, _, _ = orc.vertex_from_bump(q["bump"], q["rgb"], q["mask"].astype(np.uint8), prm(*q["shift"]), 1)
+        sel = cm > 10
+        assert np.abs(v_live[i0:i0 + cm.shape[0], j0:j0 + cm.shape[1]][sel] - v_crop[sel]).max() < 2e-5
+    rg.close()
