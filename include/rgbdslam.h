@@ -298,6 +298,38 @@ int rgbdslam_seed_labels(rgbdslam_ctx *ctx, uint8_t *Label, const float *VMap, c
                          const float *pose16_host, const float *Equations_dev, int nbPlans,
                          float epsilon, float alpha, int n, int m);
 
+/* ---- plane detection front end: RG::DetectPrimitives, D1/RG.cpp:277-338 --------------- */
+/* Kernel.cuh: void gpu_cpyN(cv::gpu::DevMem2D_<unsigned char> mat, float *NMap, int n, int m, int chnl) */
+int rgbdslam_gpu_cpy_n(rgbdslam_ctx *ctx, uint8_t *mat, size_t pitch, const float *NMap, int n, int m, int chnl);
+/* cv::gpu::Canny(img, edges, low, high, 3) as called at RG.cpp:296-302 (OpenCV 2.4, third party, restated from
+ * its published algorithm: 3x3 Sobel, L1 magnitude, thresholds swapped if low > high, 8-connected hysteresis).
+ * work_labels: n*m int32, work_bytes: 2*n*m bytes of scratch. */
+int rgbdslam_canny(rgbdslam_ctx *ctx, const uint8_t *img, size_t img_pitch, uint8_t *edges, size_t edges_pitch,
+                   double low_thresh, double high_thresh, int32_t *work_labels, uint8_t *work_bytes, int n, int m);
+/* Kernel.cuh: void gpu_Sum(DevMem2D_<uchar> Out, InR, InG, InB, int n, int m) */
+int rgbdslam_gpu_sum(rgbdslam_ctx *ctx, uint8_t *out, size_t out_pitch, const uint8_t *inR, size_t r_pitch,
+                     const uint8_t *inG, size_t g_pitch, const uint8_t *inB, size_t b_pitch, int n, int m);
+/* Kernel.cuh: void gpu_Discont(DevMem2D_<uchar> mat, float *VMap, int n, int m, float thresh) */
+int rgbdslam_gpu_discont(rgbdslam_ctx *ctx, uint8_t *mat, size_t pitch, const float *VMap, int n, int m, float thresh);
+/* Kernel.cuh: void gpu_Thresh(DevMem2D_<uchar> Out, DevMem2D_<uchar> In, unsigned char thresh, unsigned char *Label, int n, int m) */
+int rgbdslam_gpu_thresh(rgbdslam_ctx *ctx, uint8_t *out, size_t out_pitch, const uint8_t *in, size_t in_pitch,
+                        uint8_t thresh, const uint8_t *Label, int n, int m);
+/* cv::erode(src, dst, getStructuringElement(MORPH_ELLIPSE, Size(5,5))) of RG.cpp:320-326 (CPU in the reference) */
+int rgbdslam_erode_ellipse5(rgbdslam_ctx *ctx, uint8_t *dst, size_t dst_pitch, const uint8_t *src, size_t src_pitch,
+                            int n, int m);
+/* Utilities.h: void FindBlobs(const cv::Mat &binary, std::vector<std::vector<cv::Point2i>> &blobs) (CPU flood fill
+ * in the reference).  blob[p] = raster index of the first pixel of p's 4-connected component (-1 = background):
+ * ascending first-pixel index IS FindBlobs' blob order, and a blob's points are the pixels carrying its index in
+ * raster order.  sizes[first pixel] = blob size, 0 elsewhere.  Both n*m int32. */
+int rgbdslam_find_blobs(rgbdslam_ctx *ctx, const uint8_t *binary, size_t pitch, int32_t *blob, int32_t *sizes,
+                        int n, int m);
+/* RG.cpp:293-338 in one call (3 x (gpu_cpyN + Canny) + gpu_Sum + gpu_Discont + gpu_Thresh + erode + FindBlobs) without
+ * the intermediate images.  Label may be NULL (the reference clears it just before, RG.cpp:313).
+ * work_labels: 3*n*m int32, work_bytes: 8*n*m bytes of scratch. */
+int rgbdslam_detect_regions(rgbdslam_ctx *ctx, const float *NMap, const float *VMap, const uint8_t *Label,
+                            double canny_low, double canny_high, float thresh_discont, uint8_t thresh_edge,
+                            int32_t *blob, int32_t *sizes, int32_t *work_labels, uint8_t *work_bytes, int n, int m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -336,3 +336,81 @@ class Slam:
         if name.startswith("RGBb"):
             return raw.reshape(self.N_prim, self.M_prim, 3)
         return raw.reshape(self.N_prim, self.M_prim)
+
+
+# ---- plane detection ---------------------------------------------------------------
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def cpy_n(nmap, chnl):
+    n, m, _ = nmap.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_cpy_n(_p(out), _p(_f32(nmap)), n, m, int(chnl))
+    return out
+
+
+def canny(img, low=120.0, high=30.0):
+    n, m = img.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_canny(_p(_u8(img)), _p(out), C.c_double(low), C.c_double(high), n, m)
+    return out
+
+
+def edge_sum(r, g, b):
+    n, m = r.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_sum(_p(out), _p(_u8(r)), _p(_u8(g)), _p(_u8(b)), n, m)
+    return out
+
+
+def discont(mat, vmap, thresh=0.03):
+    n, m = mat.shape
+    out = _u8(mat).copy()
+    lib().orc_discont(_p(out), _p(_f32(vmap)), n, m, C.c_float(thresh))
+    return out
+
+
+def thresh(img, label, t=20):
+    n, m = img.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_thresh(_p(out), _p(_u8(img)), C.c_uint8(t), _p(_u8(label)), n, m)
+    return out
+
+
+def erode_ellipse5(img):
+    n, m = img.shape
+    out = np.empty((n, m), np.uint8)
+    lib().orc_erode_ellipse5(_p(out), _p(_u8(img)), n, m)
+    return out
+
+
+def find_blobs(binary):
+    n, m = binary.shape
+    blob = np.empty((n, m), np.int32)
+    sizes = np.empty((n, m), np.int32)
+    lib().orc_find_blobs(_p(_u8(binary)), _p(blob), _p(sizes), n, m)
+    return blob, sizes
+
+
+def fit_planes(blob, sizes, vmap, nmap, pose, label, min_size=5000, min_normals=1000, max_planes=50):
+    n, m = blob.shape
+    eq = np.zeros((max_planes, 10), np.float32)
+    ce = np.zeros((max_planes, 3), np.float32)
+    lab = _u8(label).copy()
+    lib().orc_fit_planes.restype = C.c_int
+    nb = lib().orc_fit_planes(_p(np.ascontiguousarray(blob, np.int32)), _p(np.ascontiguousarray(sizes, np.int32)), _p(_f32(vmap)),
+                              _p(_f32(nmap)), _p(_f32(pose)), _p(lab), _p(eq), _p(ce), n, m, int(min_size), int(min_normals),
+                              int(max_planes))
+    return nb, eq[:nb], ce[:nb], lab
+
+
+def detect_regions(nmap, vmap, label=None):
+    """RG.cpp:293-338 up to the blob list: -> (blob, sizes, binary)."""
+    n, m, _ = nmap.shape
+    e = [canny(cpy_n(nmap, c)) for c in range(3)]
+    img = discont(edge_sum(*e), vmap, 0.03)
+    img2 = thresh(img, np.zeros((n, m), np.uint8) if label is None else label, 20)
+    binary = (erode_ellipse5(img2) > 0).astype(np.uint8)
+    blob, sizes = find_blobs(binary)
+    return blob, sizes, binary

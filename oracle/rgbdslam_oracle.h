@@ -159,4 +159,17 @@ const void *orc_slam_buffer(const orc_slam *s, const char *name, size_t *bytes);
 #ifdef __cplusplus
 }
 #endif
+/* ---- plane detection (detect_oracle.c) -- D1/RG.cpp:277-694, D1/Kernel.cu:684-781,
+ *      D1/Utilities.cpp:1052-1092; Canny / erode / flood fill restated from OpenCV 2.4's published algorithms */
+void orc_cpy_n(uint8_t *mat, const float *NMap, int n, int m, int chnl);
+void orc_canny(const uint8_t *img, uint8_t *edges, double low_thresh, double high_thresh, int n, int m);
+void orc_sum(uint8_t *out, const uint8_t *r, const uint8_t *g, const uint8_t *b, int n, int m);
+void orc_discont(uint8_t *mat, const float *VMap, int n, int m, float thresh);
+void orc_thresh(uint8_t *out, const uint8_t *in, uint8_t thresh, const uint8_t *Label, int n, int m);
+void orc_erode_ellipse5(uint8_t *dst, const uint8_t *src, int n, int m);
+void orc_find_blobs(const uint8_t *binary, int32_t *blob, int32_t *sizes, int n, int m);
+int orc_fit_planes(const int32_t *blob, const int32_t *sizes, const float *VMap, const float *NMap, const float *pose,
+                   uint8_t *Label, float *equations, float *centers, int n, int m, int min_size, int min_normals,
+                   int max_planes);
+
 #endif

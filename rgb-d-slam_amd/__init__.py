@@ -170,6 +170,37 @@ class Context:
                                                int(plane_lo), int(plane_hi), n, m, C.c_ushort(min_conf), C.c_float(thresh),
                                                int(inverse_normals), int(variant)), "bump_mesh_batch")
 
+    # ---- plane detection front end ----
+    def gpu_cpy_n(self, mat, nmap, n, m, chnl, pitch=None):
+        _chk(self.lib.rgbdslam_gpu_cpy_n(self._h, _ptr(mat), C.c_size_t(pitch or m), _ptr(nmap), n, m, int(chnl)), "gpu_cpy_n")
+
+    def canny(self, img, edges, work_labels, work_bytes, n, m, low=120.0, high=30.0, img_pitch=None, edges_pitch=None):
+        _chk(self.lib.rgbdslam_canny(self._h, _ptr(img), C.c_size_t(img_pitch or m), _ptr(edges), C.c_size_t(edges_pitch or m),
+                                     C.c_double(low), C.c_double(high), _ptr(work_labels), _ptr(work_bytes), n, m), "canny")
+
+    def gpu_sum(self, out, r, g, b, n, m):
+        s = C.c_size_t(m)
+        _chk(self.lib.rgbdslam_gpu_sum(self._h, _ptr(out), s, _ptr(r), s, _ptr(g), s, _ptr(b), s, n, m), "gpu_sum")
+
+    def gpu_discont(self, mat, vmap, n, m, thresh=0.03):
+        _chk(self.lib.rgbdslam_gpu_discont(self._h, _ptr(mat), C.c_size_t(m), _ptr(vmap), n, m, C.c_float(thresh)), "gpu_discont")
+
+    def gpu_thresh(self, out, img, label, n, m, thresh=20):
+        _chk(self.lib.rgbdslam_gpu_thresh(self._h, _ptr(out), C.c_size_t(m), _ptr(img), C.c_size_t(m), C.c_uint8(thresh), _ptr(label),
+                                          n, m), "gpu_thresh")
+
+    def erode_ellipse5(self, dst, src, n, m):
+        _chk(self.lib.rgbdslam_erode_ellipse5(self._h, _ptr(dst), C.c_size_t(m), _ptr(src), C.c_size_t(m), n, m), "erode_ellipse5")
+
+    def find_blobs(self, binary, blob, sizes, n, m, pitch=None):
+        _chk(self.lib.rgbdslam_find_blobs(self._h, _ptr(binary), C.c_size_t(pitch or m), _ptr(blob), _ptr(sizes), n, m), "find_blobs")
+
+    def detect_regions(self, nmap, vmap, label, blob, sizes, work_labels, work_bytes, n, m, canny_low=120.0, canny_high=30.0,
+                       thresh_discont=0.03, thresh_edge=20):
+        _chk(self.lib.rgbdslam_detect_regions(self._h, _ptr(nmap), _ptr(vmap), _ptr(label), C.c_double(canny_low), C.c_double(canny_high),
+                                              C.c_float(thresh_discont), C.c_uint8(thresh_edge), _ptr(blob), _ptr(sizes),
+                                              _ptr(work_labels), _ptr(work_bytes), n, m), "detect_regions")
+
     def transform_vertex_map(self, vmap, rgbd, n, m):
         _chk(self.lib.rgbdslam_transform_vertex_map(self._h, _ptr(vmap), _ptr(rgbd), n, m), "transform_vertex_map")
 
