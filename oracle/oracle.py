@@ -304,6 +304,14 @@ class Slam:
     def __del__(self):
         self.close()
 
+    def detect_planes(self, min_size=5000, min_normals=1000, max_planes=50):
+        """RG::Finish first branch: DetectPrimitives + CreatePrimitives -> (equations [k,10], centers [k,3])."""
+        eq = np.zeros((max_planes, 10), np.float32)
+        ce = np.zeros((max_planes, 3), np.float32)
+        lib().orc_slam_detect_planes.restype = C.c_int
+        nb = lib().orc_slam_detect_planes(self._h, int(min_size), int(min_normals), _p(eq), _p(ce))
+        return eq[:nb], ce[:nb]
+
     def set_planes(self, equations, centers):
         eq = _f32(equations)
         lib().orc_slam_set_planes(self._h, _p(eq), _p(_f32(centers)), eq.size // 10)

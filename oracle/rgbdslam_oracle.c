@@ -1096,7 +1096,8 @@ static void pack_pose(const float *R, const float *t, float *P) {               
     P[3] = 0.0f; P[7] = 0.0f; P[11] = 0.0f; P[15] = 1.0f;
 }
 
-void orc_slam_set_planes(orc_slam *s, const float *eq, const float *centers, int nb) {
+/* planes from equations + centres: the Primitive part of CreatePrimitives (RG.cpp:703-741) */
+static int install_planes(orc_slam *s, const float *eq, const float *centers, int nb) {
     if (nb > s->max_planes) nb = s->max_planes;
     size_t C = (size_t)s->N_prim * s->M_prim;
     for (int k = 0; k < nb; k++) {
@@ -1121,9 +1122,45 @@ void orc_slam_set_planes(orc_slam *s, const float *eq, const float *centers, int
         Pm[8] = E[3]; Pm[9] = E[4]; Pm[10] = E[5]; Pm[11] = E[6]; Pm[12] = E[7]; Pm[13] = E[8];
     }
     s->nb_planes = nb;
+    return nb;
+}
+
+void orc_slam_set_planes(orc_slam *s, const float *eq, const float *centers, int nb) {
+    nb = install_planes(s, eq, centers, nb);
     float pose[16];
     pack_pose(s->poseR, s->poset, pose);
     orc_seed_labels(s->Label, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, s->n, s->m);
+}
+
+/* RG::Finish's first branch (RG.cpp:154-175): DetectPrimitives (277-694) + CreatePrimitives (699-793) on the
+ * current model frame.  equations_out / centers_out (may be NULL) receive the fitted planes.  Returns the count. */
+int orc_slam_detect_planes(orc_slam *s, int min_size, int min_normals, float *equations_out, float *centers_out) {
+    int n = s->n, m = s->m;
+    size_t P = (size_t)n * m;
+    float pose[16];
+    pack_pose(s->poseR, s->poset, pose);
+    uint8_t *ch = (uint8_t *)malloc(P), *e[3], *img = (uint8_t *)malloc(P), *img2 = (uint8_t *)malloc(P), *er = (uint8_t *)malloc(P);
+    for (int c = 0; c < 3; c++) {
+        e[c] = (uint8_t *)malloc(P);
+        orc_cpy_n(ch, s->N, n, m, c);                                             /* RG.cpp:295-302 */
+        orc_canny(ch, e[c], 120.0, 30.0, n, m);
+    }
+    orc_sum(img, e[0], e[1], e[2], n, m);                                          /* RG.cpp:304 */
+    orc_discont(img, s->V, n, m, 0.03f);                                           /* RG.cpp:307 */
+    memset(s->Label, 0, P);                                                        /* RG.cpp:313 */
+    orc_thresh(img2, img, 20, s->Label, n, m);                                     /* RG.cpp:315 */
+    orc_erode_ellipse5(er, img2, n, m);                                            /* RG.cpp:320-326 */
+    int32_t *blob = (int32_t *)malloc(P * 4), *sizes = (int32_t *)malloc(P * 4);
+    orc_find_blobs(er, blob, sizes, n, m);                                         /* RG.cpp:336-338 (binary = er > 0) */
+    float *eq = (float *)calloc((size_t)10 * s->max_planes, 4), *ce = (float *)calloc((size_t)3 * s->max_planes, 4);
+    int nb = orc_fit_planes(blob, sizes, s->V, s->N, pose, s->Label, eq, ce, n, m, min_size, min_normals, s->max_planes);
+    nb = install_planes(s, eq, ce, nb);
+    if (nb > 0) orc_segment(s->Label, s->LabelSwap, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, n, m);   /* RG.cpp:786 */
+    if (equations_out) memcpy(equations_out, eq, (size_t)40 * nb);
+    if (centers_out) memcpy(centers_out, ce, (size_t)12 * nb);
+    free(ch); free(img); free(img2); free(er); free(blob); free(sizes); free(eq); free(ce);
+    for (int c = 0; c < 3; c++) free(e[c]);
+    return nb;
 }
 
 static void model_from_frame(orc_slam *s) {                                      /* Frame.cpp:335-370 */

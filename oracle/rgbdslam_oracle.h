@@ -149,6 +149,7 @@ void orc_slam_destroy(orc_slam *s);
 /* Inject plane equations (n,e1,e2,d) x nb + centres (xyz) and create primitives as
  * RG::CreatePrimitives does (D1/RG.cpp:699-793); seeds labels on the current model frame. */
 void orc_slam_set_planes(orc_slam *s, const float *equations, const float *centers, int nb);
+int orc_slam_detect_planes(orc_slam *s, int min_size, int min_normals, float *equations_out, float *centers_out);
 /* One display() pass. Returns 1 tracked, 0 lost (model re-seeded), 2 first frame (model seeded). */
 int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr);
 void orc_slam_get_pose(const orc_slam *s, float *R9_cm, float *t3);

@@ -348,6 +348,16 @@ class RG:
     def save_trajectory(self, filename):
         _hchk(self.lib.slamhost_rg_save_trajectory(self._h, os.fsencode(filename)), "save_trajectory")
 
+    def detect_planes(self, min_size=-1, min_normals=-1, cap=50):
+        """First branch of RG::Finish (D1/RG.cpp:154-175): DetectPrimitives + CreatePrimitives on the current model frame.
+        -> (equations [k,10], centers [k,3]); min_size / min_normals override MIN_SIZE_PLAN (5000) / 1000 for small images."""
+        import numpy as np
+        nb = C.c_int()
+        _hchk(self.lib.slamhost_rg_detect_planes(self._h, int(min_size), int(min_normals), C.byref(nb)), "detect_planes")
+        eq, ce = np.zeros((cap, 10), np.float32), np.zeros((cap, 3), np.float32)
+        _hchk(self.lib.slamhost_rg_get_planes(self._h, C.c_void_p(eq.ctypes.data), C.c_void_p(ce.ctypes.data), cap), "get_planes")
+        return eq[:nb.value], ce[:nb.value]
+
     def save_model(self, directory, indx):
         """Saving half of RG::Finish + SaveThread (D1/RG.cpp:16-59): cleaned planes + key frame in the reference's dump format."""
         _hchk(self.lib.slamhost_rg_save_model(self._h, os.fsencode(directory), int(indx)), "save_model")

@@ -2,6 +2,8 @@
 // No kernels here: all device work goes through the C ABI of include/rgbdslam.h.
 #include "rgbdslam_host.hpp"
 
+#include <algorithm>
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -643,7 +645,99 @@ void RG::SetPlanes(const float *equations, const float *centers, int nbPlan) {
     CreatePrimitives(pose);
 }
 
-void RG::CreatePrimitives(float *pose) {
+// RG.cpp:277-694.  Image stages on the GPU, median fit on the host (as in the reference, RG.cpp:393-679).
+void RG::DetectPrimitives(float *pose) {
+    const int n = _predicted_frame->_n, m = _predicted_frame->_m;
+    const size_t P = (size_t)n * m;
+    hipStream_t s = ctx_stream(_ctx);
+    if (_blob_dev.count != P) {
+        _blob_dev.alloc(P, false); _blob_sizes_dev.alloc(P, false); _detect_labels.alloc(3 * P, false); _detect_bytes.alloc(8 * P, false);
+    }
+    hip_check(hipMemsetAsync(_predicted_frame->_Label_dev, 0, P, s), "memset label");                      // RG.cpp:313
+    check(rgbdslam_detect_regions(_ctx, _predicted_frame->getNMap(), _predicted_frame->getVMap(), nullptr, 120.0, 30.0, 0.03f, 20,
+                                  _blob_dev.p, _blob_sizes_dev.p, _detect_labels.p, _detect_bytes.p, n, m), "detect_regions");
+    std::vector<int32_t> blob(P), sizes(P);
+    std::vector<float> VMap_cpu(3 * P), NMap_cpu(3 * P);                              // RG.cpp:394-396
+    std::vector<uint8_t> Label_cpu(P, 0);
+    hip_check(hipMemcpyAsync(blob.data(), _blob_dev.p, 4 * P, hipMemcpyDeviceToHost, s), "blob download");
+    hip_check(hipMemcpyAsync(sizes.data(), _blob_sizes_dev.p, 4 * P, hipMemcpyDeviceToHost, s), "sizes download");
+    hip_check(hipMemcpyAsync(VMap_cpu.data(), _predicted_frame->getVMap(), 12 * P, hipMemcpyDeviceToHost, s), "VMap download");
+    hip_check(hipMemcpyAsync(NMap_cpu.data(), _predicted_frame->getNMap(), 12 * P, hipMemcpyDeviceToHost, s), "NMap download");
+    hip_check(hipStreamSynchronize(s), "sync");
+
+    _nbPlan = 0;                                                                      // RG.cpp:401
+    _Equations.clear(); _Centers.clear();
+    // blobs in FindBlobs' order = ascending first-pixel index; a blob's points = its pixels in raster order
+    std::vector<size_t> roots;
+    for (size_t p = 0; p < P; p++)
+        if (sizes[p] > min_size_plan) roots.push_back(p);                             // RG.cpp:342-347
+    _Detect = !roots.empty();                                                         // RG.cpp:385-390
+    if (!_Detect) return;
+    const int max_labels = 255;
+    for (size_t root : roots) {
+        if (_nbPlan >= max_labels) break;
+        const int curr_size = sizes[root];
+        std::vector<size_t> px;
+        px.reserve((size_t)curr_size);
+        for (size_t p = root; p < P && (int)px.size() < curr_size; p++)
+            if (blob[p] == (int32_t)root) px.push_back(p);
+        std::vector<float> Nx((size_t)curr_size, 0.0f), Ny((size_t)curr_size, 0.0f), Nz((size_t)curr_size, 0.0f);
+        int count = 0;
+        for (int j = 0; j < curr_size; j++) {                                         // RG.cpp:479-497
+            const float *N = &NMap_cpu[3 * px[j]];
+            if (N[0] == 0.0f && N[1] == 0.0f && N[2] == 0.0f) continue;               // such entries stay 0 in the lists
+            count++;
+            Nx[j] = (N[0] * pose[0] + N[1] * pose[4]) + N[2] * pose[8];
+            Ny[j] = (N[0] * pose[1] + N[1] * pose[5]) + N[2] * pose[9];
+            Nz[j] = (N[0] * pose[2] + N[1] * pose[6]) + N[2] * pose[10];
+        }
+        if (count < min_normals_plan) continue;                                       // RG.cpp:500-516
+        std::sort(Nx.begin(), Nx.end()); std::sort(Ny.begin(), Ny.end()); std::sort(Nz.begin(), Nz.end());   // RG.cpp:521-533
+        float nmle[3] = {Nx[Nx.size() / 2], Ny[Ny.size() / 2], Nz[Nz.size() / 2]};
+        float norm_nmle = sqrtf((nmle[0] * nmle[0] + nmle[1] * nmle[1]) + nmle[2] * nmle[2]);
+        nmle[0] = nmle[0] / norm_nmle; nmle[1] = nmle[1] / norm_nmle; nmle[2] = nmle[2] / norm_nmle;
+        std::vector<float> Dists((size_t)curr_size);
+        float center_curr[3] = {0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < curr_size; j++) {                                         // RG.cpp:557-578
+            const float *V = &VMap_cpu[3 * px[j]];
+            float pt[3];
+            pt[0] = ((V[0] * pose[0] + V[1] * pose[4]) + V[2] * pose[8]) + pose[12];
+            pt[1] = ((V[0] * pose[1] + V[1] * pose[5]) + V[2] * pose[9]) + pose[13];
+            pt[2] = ((V[0] * pose[2] + V[1] * pose[6]) + V[2] * pose[10]) + pose[14];
+            center_curr[0] = center_curr[0] + pt[0]; center_curr[1] = center_curr[1] + pt[1]; center_curr[2] = center_curr[2] + pt[2];
+            Dists[j] = (pt[0] * nmle[0] + pt[1] * nmle[1]) + pt[2] * nmle[2];
+            Label_cpu[px[j]] = (uint8_t)(_nbPlan + 1);
+        }
+        for (int k = 0; k < 3; k++) _Centers.push_back(center_curr[k] / (float)curr_size);   // RG.cpp:581-583
+        std::sort(Dists.begin(), Dists.end());                                        // RG.cpp:592-598
+        const float dist = Dists[Dists.size() / 2];
+        float e1[3], e2[3];                                                           // RG.cpp:607-637
+        if (nmle[0] > nmle[1] && nmle[0] > nmle[2]) { e1[0] = -nmle[1]; e1[1] = nmle[0]; e1[2] = 0.0f; }
+        else if (nmle[1] > nmle[0] && nmle[1] > nmle[2]) { e1[0] = 0.0f; e1[1] = -nmle[2]; e1[2] = nmle[1]; }
+        else { e1[0] = nmle[2]; e1[1] = 0.0f; e1[2] = -nmle[0]; }
+        float norm_e = sqrtf((e1[0] * e1[0] + e1[1] * e1[1]) + e1[2] * e1[2]);
+        e1[0] /= norm_e; e1[1] /= norm_e; e1[2] /= norm_e;
+        e2[0] = nmle[1] * e1[2] - nmle[2] * e1[1];
+        e2[1] = nmle[2] * e1[0] - nmle[0] * e1[2];
+        e2[2] = nmle[0] * e1[1] - nmle[1] * e1[0];
+        const float eq[10] = {nmle[0], nmle[1], nmle[2], e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], dist};
+        _Equations.insert(_Equations.end(), eq, eq + 10);
+        _nbPlan++;
+    }
+    hip_check(hipMemcpy(_predicted_frame->_Label_dev, Label_cpu.data(), P, hipMemcpyHostToDevice), "label upload");   // RG.cpp:590
+}
+
+int RG::DetectPlanes() {                                                              // RG.cpp:154-175
+    if (fused) Sync();
+    float pose[16];
+    pack_pose(_poseR, _poset, pose);
+    _graph->Clear();
+    DetectPrimitives(pose);
+    CreatePrimitives(pose, true);
+    return _nbPlan;
+}
+
+void RG::CreatePrimitives(float *pose, bool labels_from_detection) {
     std::vector<int> Assoc(_nbPlan, -1);
     int count = 0;
     for (int i = 0; i < _nbPlan; i++) {
@@ -673,9 +767,14 @@ void RG::CreatePrimitives(float *pose) {
     if (count == 0) return;
     _Equations_dev.alloc(10 * (size_t)count, false);                                 // RG.cpp:779-780
     hip_check(hipMemcpy(_Equations_dev.p, _Equations.data(), 40 * (size_t)count, hipMemcpyHostToDevice), "Equations");
-    // The reference grows the labels produced by DetectPrimitives with Segment_cu (RG.cpp:786).
-    // Plane detection is not built yet: labels are seeded by plane membership with
-    // the same thresholds (ACCEPT_THRESH 0.1, 0.8).
+    if (labels_from_detection) {                                                     // RG.cpp:786: grow the blob labels
+        check(rgbdslam_segment(_ctx, _predicted_frame->_Label_dev, _predicted_frame->_Label_dev_swap, _predicted_frame->getVMap(),
+                               _predicted_frame->getNMap(), pose, _Equations_dev.p, _nbPlan, 0.1f, 0.8f, _predicted_frame->_n,
+                               _predicted_frame->_m), "Segment_cu");
+        return;
+    }
+    // injected planes (SetPlanes) come without blob labels: they are seeded by plane membership with the
+    // same thresholds (ACCEPT_THRESH 0.1, 0.8)
     check(rgbdslam_seed_labels(_ctx, _predicted_frame->_Label_dev, _predicted_frame->getVMap(), _predicted_frame->getNMap(), pose,
                                _Equations_dev.p, _nbPlan, 0.1f, 0.8f, _predicted_frame->_n, _predicted_frame->_m), "seed_labels");
 }
@@ -1057,6 +1156,25 @@ int slamhost_model_keyframe(void *h, int which, int *rows, int *cols, uint16_t *
     const slam::Image &I = which ? M->rgb : M->depth;
     *rows = I.rows; *cols = I.cols;
     if (buf) memcpy(buf, I.data.data(), I.data.size());
+    return 0;
+}
+// ---- plane detection --------------------------------------------------------------------
+int slamhost_rg_detect_planes(void *rg, int min_size, int min_normals, int *nb) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    if (min_size >= 0) r->min_size_plan = min_size;
+    if (min_normals >= 0) r->min_normals_plan = min_normals;
+    int k = 0;
+    FACADE_TRY(k = r->DetectPlanes());
+    if (nb) *nb = k;
+    return 0;
+}
+int slamhost_rg_get_planes(void *rg, float *equations, float *centers, int cap) {
+    if (!rg || !equations || !centers) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    if (r->_nbPlan > cap) return RGBDSLAM_E_LIMIT;
+    memcpy(equations, r->_Equations.data(), 40 * (size_t)r->_nbPlan);
+    memcpy(centers, r->_Centers.data(), 12 * (size_t)r->_nbPlan);
     return 0;
 }
 // ---- host-logic test hooks (CPU only: no device work) ---------------------------------------------

@@ -203,7 +203,15 @@ public:
     bool AlignFrameGaussNewton();                                  // RG.cpp:797-932
     // plane injection: stands in for DetectPrimitives then runs CreatePrimitives
     void SetPlanes(const float *equations, const float *centers, int nbPlan);
-    void CreatePrimitives(float *pose);                            // RG.cpp:699-793
+    void CreatePrimitives(float *pose, bool labels_from_detection = false);   // RG.cpp:699-793
+    // plane detection: RG.cpp:277-694.  The image stages run on the GPU (rgbdslam_detect_regions);
+    // the median plane fit is host code as in the reference.  DetectPlanes = the first branch of RG::Finish
+    // (RG.cpp:154-175): DetectPrimitives + CreatePrimitives on the current model frame; returns the plane count.
+    void DetectPrimitives(float *pose);
+    int DetectPlanes();
+    int min_size_plan = 5000;                                      // MIN_SIZE_PLAN (Utilities.h:85)
+    int min_normals_plan = 1000;                                   // RG.cpp:500
+    bool _Detect = false;
     // one pass of display() (GP-demo.cpp:138-296): 2 = model seeded, 1 = tracked, 0 = lost
     int Step();
     // fused pipeline (default): the whole pass is enqueued without a host sync; the pose, status and
@@ -241,6 +249,8 @@ private:
     DevBuf<float> _history_dev;
     float *_history_host = nullptr;
     int _history_synced = 0;
+    DevBuf<int32_t> _blob_dev, _blob_sizes_dev, _detect_labels;
+    DevBuf<uint8_t> _detect_bytes;
     std::vector<int> _traj_count;                                  // dataset index of every processed frame
     std::vector<Mat3> _traj_R;                                     // unfused path: poses pushed by Step()
     std::vector<Vec3> _traj_t;

@@ -303,3 +303,47 @@ def test_save_model_dump_round_trip(pkg, orc, synth, tmp_path):
         sel = cm > 10
         assert np.abs(v_live[i0:i0 + cm.shape[0], j0:j0 + cm.shape[1]][sel] - v_crop[sel]).max() < 2e-5
     rg.close()
+
+
+@pytest.mark.parametrize("shape,min_size,fused", [((120, 160), 300, True), ((120, 160), 300, False), ((480, 640), 5000, True)])
+def test_loop_with_detected_planes(pkg, orc, synth, shape, min_size, fused):
+    """SURVEY 8f N1: the planes come from RG::DetectPlanes (DetectPrimitives + CreatePrimitives, RG.cpp:154-175,
+    277-793) instead of being injected: GPU image stages + host median fit against the oracle's restatement --
+    equations, centres, grown labels and the Bump images fused afterwards, all bit-exact."""
+    n, m = shape
+    frames, N_prim = 6, 512 if n < 480 else 1024
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(frames, n, m, calib)
+    ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg.set_fused(fused)
+    for f, (d, c) in enumerate(seq):
+        st_ref = ref.step(d, c)
+        rg.load_frame(d, c)
+        assert rg.step() == st_ref
+        if f == 2:
+            eq_r, ce_r = ref.detect_planes(min_size, 200 if n < 480 else 1000)
+            eq, ce = rg.detect_planes(min_size, 200 if n < 480 else 1000)
+            assert len(eq_r) == 3, "the corner scene has three walls"
+            same(eq, eq_r, "equations")
+            same(ce, ce_r, "centres")
+            same(rg.buffer("Label"), ref.buffer("Label"), "labels after Segment_cu")
+            # the fitted planes are the scene's planes (up to the sign / basis the median fit picks)
+            eq0, _ = synth.plane_equations()
+            for k in range(3):
+                best = max(abs(float(np.dot(eq[k, :3], eq0[j, :3]))) for j in range(3))
+                assert best > 0.999
+                assert abs(float(np.dot(eq[k, :3], np.cross(eq[k, 3:6], eq[k, 6:9]))) - 1.0) < 1e-4   # right-handed orthonormal basis
+    R, t = rg.pose()
+    Rr, tr = ref.pose()
+    same(np.array(R, np.float32), Rr, "poseR")
+    same(np.array(t, np.float32), tr, "poset")
+    for name in ("VMap", "RGBD", "Mask", "Label"):
+        same(rg.buffer(name), ref.buffer(name), name)
+    for k in range(3):
+        mk = ref.buffer("Maskb%d" % k)
+        assert (mk > 10).sum() > 100
+        same(rg.buffer("Maskb%d" % k), mk, "Maskb%d" % k)
+        same(rg.buffer("Bump%d" % k), ref.buffer("Bump%d" % k), "Bump%d" % k)
+    rg.close()
+    ref.close()
