@@ -115,37 +115,76 @@ __device__ __forceinline__ void cc_union(int *label, int a, int b) {
         a = old;                                                // a was re-parented meanwhile: merge its new parent with b
     }
 }
-__global__ void k_cc_init(const uint8_t *__restrict__ mask, size_t pitch, int *__restrict__ label, int n, int m) {
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
-    size_t base = (size_t)blockIdx.z * n * m;
+// A wavefront is one 64-pixel row segment (block = 64 x 4).  Horizontal runs inside a segment are resolved with
+// ballots instead of unions: a pixel starts out labelled with the first pixel of its run.
+__global__ __launch_bounds__(TILE_W *TILE_H)
+void k_cc_init(const uint8_t *__restrict__ mask, size_t pitch, int *__restrict__ label, int n, int m) {
+    const int lane = threadIdx.x;
+    int j = blockIdx.x * TILE_W + lane, i = blockIdx.y * TILE_H + threadIdx.y;
+    const bool in = i < n && j < m;
+    const bool fg = in && mask[(size_t)blockIdx.z * n * pitch + (size_t)i * pitch + j] != 0;
+    const unsigned long long bits = __ballot(fg);
+    if (!in) return;
     int p = i * m + j;
-    label[base + p] = mask[(size_t)blockIdx.z * n * pitch + (size_t)i * pitch + j] ? p : -1;
+    int v = -1;
+    if (fg) {
+        unsigned long long zeros = ~bits & ((1ull << lane) - 1ull);
+        int start = zeros ? 64 - __builtin_clzll(zeros) : 0;           // lane after the highest background lane below this one
+        v = p - (lane - start);
+    }
+    label[(size_t)blockIdx.z * n * m + p] = v;
 }
+// Unions that are still needed: segment starts with their left neighbour, and ONE union per interval in which a
+// run touches a run of the row above (the other pixels of the interval are connected through the runs).
 template <int CONN>
-__global__ void k_cc_merge(int *__restrict__ label, int n, int m) {
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
+__global__ __launch_bounds__(TILE_W *TILE_H)
+void k_cc_merge(int *__restrict__ label, int n, int m) {
+    const int lane = threadIdx.x;
+    int j = blockIdx.x * TILE_W + lane, i = blockIdx.y * TILE_H + threadIdx.y;
     int *L = label + (size_t)blockIdx.z * n * m;
-    int p = i * m + j;
-    if (L[p] < 0) return;
-    if (j > 0 && L[p - 1] >= 0) cc_union(L, p, p - 1);
-    if (i > 0 && L[p - m] >= 0) cc_union(L, p, p - m);
-    if (CONN == 8 && i > 0) {
-        if (j > 0 && L[p - m - 1] >= 0) cc_union(L, p, p - m - 1);
-        if (j < m - 1 && L[p - m + 1] >= 0) cc_union(L, p, p - m + 1);
+    const bool in = i < n && j < m;
+    const int p = i * m + j;
+    const bool fg = in && L[p] >= 0;
+    const bool upfg = in && i > 0 && L[p - m] >= 0;
+    const unsigned long long bits = __ballot(fg), upbits = __ballot(upfg);
+    if (!fg) return;
+    const bool left = lane > 0 ? ((bits >> (lane - 1)) & 1ull) != 0 : false;       // left neighbour in this segment is foreground
+    if (lane == 0 && j > 0 && L[p - 1] >= 0) cc_union(L, p, p - 1);
+    if (i == 0) return;
+    const bool ul = lane > 0 ? ((upbits >> (lane - 1)) & 1ull) != 0 : (j > 0 && L[p - m - 1] >= 0);
+    if (upfg) {
+        if (lane == 0 || !left || !ul) cc_union(L, p, p - m);
+    } else if (CONN == 8) {
+        const bool right = lane < 63 ? ((bits >> (lane + 1)) & 1ull) != 0 : false;
+        const bool ur = lane < 63 ? ((upbits >> (lane + 1)) & 1ull) != 0 : (j < m - 1 && L[p - m + 1] >= 0);
+        if (ul && !left) cc_union(L, p, p - m - 1);
+        if (ur && !(right && lane < 63)) cc_union(L, p, p - m + 1);
     }
 }
-// sizes (may be null): sizes[root] = number of pixels of the component, 0 elsewhere (cleared by the caller)
-__global__ void k_cc_flatten(int *__restrict__ label, int *__restrict__ sizes, int n, int m) {
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
+// sizes (may be null): sizes[root] = number of pixels of the component, 0 elsewhere (cleared by the caller);
+// lanes of a wave that share a root add their count with one atomic
+__global__ __launch_bounds__(TILE_W *TILE_H)
+void k_cc_flatten(int *__restrict__ label, int *__restrict__ sizes, int n, int m) {
+    const int lane = threadIdx.x;
+    int j = blockIdx.x * TILE_W + lane, i = blockIdx.y * TILE_H + threadIdx.y;
     int *L = label + (size_t)blockIdx.z * n * m;
-    int p = i * m + j;
-    if (L[p] < 0) return;
-    int root = cc_find(L, p);
-    __atomic_store_n(&L[p], root, __ATOMIC_RELAXED);
-    if (sizes) atomicAdd(&sizes[(size_t)blockIdx.z * n * m + root], 1);
+    const bool in = i < n && j < m;
+    const int p = i * m + j;
+    const bool fg = in && L[p] >= 0;
+    int root = -1;
+    if (fg) {
+        root = cc_find(L, p);
+        __atomic_store_n(&L[p], root, __ATOMIC_RELAXED);
+    }
+    if (!sizes) return;
+    unsigned long long remaining = __ballot(fg);
+    while (remaining) {                                               // wave-uniform loop: one round per distinct root
+        const int leader = __builtin_ctzll(remaining);
+        const int r0 = __shfl(root, leader);
+        const unsigned long long same = __ballot(fg && root == r0);
+        if (lane == leader) atomicAdd(&sizes[(size_t)blockIdx.z * n * m + r0], (int)__builtin_popcountll(same));
+        remaining &= ~same;
+    }
 }
 
 // ---- Canny stage 2: hysteresis = components of (weak or strong) pixels that contain a strong one ------------
