@@ -200,6 +200,15 @@ int rgbdslam_update_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_b
                             uint64_t **ClaimTab, uint32_t stamp, const float *VMap, const float *RGBD,
                             const uint8_t *Mask, const uint8_t *Label, int N_prim, int M_prim, int n,
                             int m, int plane_lo, int plane_hi);
+/* The same, gated on and posed by the frame's entry of the pose history ring (16 floats written by
+ * rgbdslam_track_frame: poseR(9, column-major) poset(3) tracked ...).  Unlike the pose block, the entry is
+ * never rewritten by the next frame, so this call may run on another stream concurrently with the next
+ * frame's tracking (the caller orders it after rgbdslam_model_merge and before the model is written again). */
+int rgbdslam_update_from_history(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab,
+                                 uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                 uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                                 const uint8_t *Label, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                 int plane_hi);
 
 /* ---- stage 4: fusion ---------------------------------------------------------------------- */
 /* Kernel.cuh:21  void MergeDepthOff(float *RGB_predicted, DevMem2D_<unsigned short> depth,

@@ -287,6 +287,11 @@ class RG:
         """True (default): fused, sync-free frame pipeline; False: one C-ABI call per reference operator."""
         _hchk(self.lib.slamhost_rg_set_fused(self._h, int(on)), "set_fused")
 
+    def set_overlap(self, on):
+        """Fused pipeline: True runs the next frame's preprocessing and the Bump update on auxiliary streams (default off:
+        measured slower than one stream at 640x480)."""
+        _hchk(self.lib.slamhost_rg_set_overlap(self._h, int(on)), "set_overlap")
+
     def history(self, first, count):
         """Poses of frames [first, first+count): rows of poseR(9, col-major) poset(3) tracked iterations level_iters 0."""
         import numpy as np

@@ -38,12 +38,19 @@ __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *
                          uint8_t *const *__restrict__ MaskTab, float *const *__restrict__ ParamTab,
                          unsigned long long *const *__restrict__ ClaimTab, uint32_t stamp,
                          const float *__restrict__ VMap, const float *__restrict__ RGBD, const uint8_t *__restrict__ Mask,
-                         const uint8_t *__restrict__ Label, PoseV P, const rgbdslam_pose_block *__restrict__ pb, int N_prim,
-                         int M_prim, int n, int m, int plane_lo, int plane_hi) {
+                         const uint8_t *__restrict__ Label, PoseV P, const rgbdslam_pose_block *__restrict__ pb,
+                         const float *__restrict__ hist, int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi) {
     if (pb) {                                         // fused pipeline: pose from the device block, gated on it
         if (pb->status[0] != 1) return;
 #pragma unroll
         for (int k = 0; k < 16; k++) P.v[k] = pb->P_glob[k];
+    } else if (hist) {                                // the frame's immutable history entry: poseR(9) poset(3) tracked ...
+        if (hist[12] != 1.0f) return;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            P.v[4 * c] = hist[3 * c]; P.v[4 * c + 1] = hist[3 * c + 1]; P.v[4 * c + 2] = hist[3 * c + 2]; P.v[4 * c + 3] = 0.0f;
+        }
+        P.v[12] = hist[9]; P.v[13] = hist[10]; P.v[14] = hist[11]; P.v[15] = 1.0f;
     }
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
@@ -150,20 +157,20 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
 // =================================================================================================
 // C ABI
 // =================================================================================================
-static int launch_update(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, uint16_t **BumpTab, uint8_t **RGBTab,
+static int launch_update(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, const float *hist, uint16_t **BumpTab, uint8_t **RGBTab,
                          uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, const float *VMap,
                          const float *RGBD, const uint8_t *Mask, const uint8_t *Label, const float *pose, int N_prim,
                          int M_prim, int n, int m, int plane_lo, int plane_hi) {
-    if (!ctx || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !VMap || !RGBD || !Mask || !Label || (!pose && !pb))
+    if (!ctx || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !VMap || !RGBD || !Mask || !Label || (!pose && !pb && !hist))
         return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;   // 23-bit pixel index in the claim key
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = pose ? pose[k] : 0.0f;
     KLAUNCH(ctx, k_update<false>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab,
-            (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, N_prim, M_prim, n, m, plane_lo, plane_hi);
+            (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, hist, N_prim, M_prim, n, m, plane_lo, plane_hi);
     KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab,
-            (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, N_prim, M_prim, n, m, plane_lo, plane_hi);
+            (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, hist, N_prim, M_prim, n, m, plane_lo, plane_hi);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -173,7 +180,7 @@ extern "C" int rgbdslam_update(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **
                                const uint8_t *Mask, const uint8_t *Label, const float *pose, int N_prim, int M_prim,
                                int n, int m, int plane_lo, int plane_hi) {
     if (!pose) return RGBDSLAM_E_ARG;
-    return launch_update(ctx, nullptr, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label, pose, N_prim,
+    return launch_update(ctx, nullptr, nullptr, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label, pose, N_prim,
                          M_prim, n, m, plane_lo, plane_hi);
 }
 
@@ -182,8 +189,18 @@ extern "C" int rgbdslam_update_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_bl
                                        const float *VMap, const float *RGBD, const uint8_t *Mask, const uint8_t *Label,
                                        int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi) {
     if (!pb) return RGBDSLAM_E_ARG;
-    return launch_update(ctx, pb, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, N_prim,
+    return launch_update(ctx, pb, nullptr, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, N_prim,
                          M_prim, n, m, plane_lo, plane_hi);
+}
+
+extern "C" int rgbdslam_update_from_history(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab,
+                                            uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                            uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                                            const uint8_t *Label, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                            int plane_hi) {
+    if (!history_entry_dev) return RGBDSLAM_E_ARG;
+    return launch_update(ctx, nullptr, history_entry_dev, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label,
+                         nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi);
 }
 
 extern "C" int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *RGBA, float *MaskOut, const uint16_t *Bump,

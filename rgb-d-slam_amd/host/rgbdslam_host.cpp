@@ -172,25 +172,70 @@ static hipStream_t ctx_stream(rgbdslam_ctx *ctx) {
 // ---- InputFrame / OffLineFrame (D1/Frame.h:19-134, D1/Frame.cpp:43-77) ----------------------------
 InputFrame::InputFrame(rgbdslam_ctx *ctx, int n, int m) : _ctx(ctx), _n(n), _m(m) {
     size_t P = (size_t)n * m;
-    _VMap_dev.alloc(3 * P);
-    _NMap_dev.alloc(3 * P);
-    _RGB_dev.alloc(3 * P);
+    _VMap_dev[0].alloc(3 * P);
+    _NMap_dev[0].alloc(3 * P);
+    _RGB_dev[0].alloc(3 * P);
 }
 
 OffLineFrame::OffLineFrame(rgbdslam_ctx *ctx, int n, int m) : InputFrame(ctx, n, m) {
-    _depth_dev_test.alloc((size_t)n * m);
-    _color_dev_test.alloc(3 * (size_t)n * m);
+    _depth_dev_test[0].alloc((size_t)n * m);
+    _color_dev_test[0].alloc(3 * (size_t)n * m);
+}
+OffLineFrame::~OffLineFrame() {
+    for (int k = 0; k < 2; k++) {
+        if (_ready[k]) (void)hipEventDestroy(_ready[k]);
+        if (_free[k]) (void)hipEventDestroy(_free[k]);
+    }
+}
+
+void OffLineFrame::EnableGradients(bool on) {
+    _gradients = on;
+    if (!on) return;
+    for (int k = 0; k < 2; k++)
+        if (_VMap_dev[k].p && !_Gx[k].p) { _Gx[k].alloc((size_t)_n * _m); _Gy[k].alloc((size_t)_n * _m); }
+}
+
+void OffLineFrame::AttachLoadStream(hipStream_t load_stream) {
+    if (_loaded_once) throw Error("AttachLoadStream: frames were already loaded", RGBDSLAM_E_STATE);
+    _load_stream = load_stream;
+    if (!load_stream) return;
+    size_t P = (size_t)_n * _m;
+    if (!_VMap_dev[1].p) {
+        _VMap_dev[1].alloc(3 * P); _NMap_dev[1].alloc(3 * P); _RGB_dev[1].alloc(3 * P);
+        _depth_dev_test[1].alloc(P); _color_dev_test[1].alloc(3 * P);
+    }
+    if (_gradients) EnableGradients(true);
+    for (int k = 0; k < 2; k++) {
+        if (!_ready[k]) hip_check(hipEventCreateWithFlags(&_ready[k], hipEventDisableTiming), "hipEventCreate");
+        if (!_free[k]) hip_check(hipEventCreateWithFlags(&_free[k], hipEventDisableTiming), "hipEventCreate");
+    }
+}
+
+void OffLineFrame::release(hipStream_t consumer) {
+    if (!_load_stream) return;
+    hip_check(hipEventRecord(_free[_cur], consumer), "hipEventRecord");
+    _free_recorded[_cur] = true;
+}
+
+// with a load stream: switch to the other buffer set and make the stream wait until that set's last reader is done
+void OffLineFrame::begin_load() {
+    if (_load_stream && _loaded_once) {
+        _cur ^= 1;
+        if (_free_recorded[_cur]) hip_check(hipStreamWaitEvent(_load_stream, _free[_cur], 0), "hipStreamWaitEvent");
+    }
+    _loaded_once = true;
 }
 
 void OffLineFrame::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
     size_t P = (size_t)_n * _m;
-    hipStream_t s = ctx_stream(_ctx);
+    begin_load();
+    hipStream_t s = _load_stream ? _load_stream : ctx_stream(_ctx);
     // GpuMat::upload x2 (Frame.cpp:56-60)
-    hip_check(hipMemcpyAsync(_depth_dev_test.p, depth_host, 2 * P, hipMemcpyHostToDevice, s), "upload depth");
-    hip_check(hipMemcpyAsync(_color_dev_test.p, bgr_host, 3 * P, hipMemcpyHostToDevice, s), "upload colour");
-    _depth_cur = _depth_dev_test.p;
-    _depth_pitch = 2 * (size_t)_m;
-    preprocess(_color_dev_test.p, 3 * (size_t)_m);
+    hip_check(hipMemcpyAsync(_depth_dev_test[_cur].p, depth_host, 2 * P, hipMemcpyHostToDevice, s), "upload depth");
+    hip_check(hipMemcpyAsync(_color_dev_test[_cur].p, bgr_host, 3 * P, hipMemcpyHostToDevice, s), "upload colour");
+    _depth_cur[_cur] = _depth_dev_test[_cur].p;
+    _depth_pitch[_cur] = 2 * (size_t)_m;
+    preprocess(_color_dev_test[_cur].p, 3 * (size_t)_m);
 }
 
 void OffLineFrame::LoadFrame(const std::string &filename_depth, const std::string &filename_color) {
@@ -210,20 +255,30 @@ void OffLineFrame::LoadFrame(const std::string &filename_depth, const std::strin
 }
 
 void OffLineFrame::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
-    _depth_cur = depth_dev;
-    _depth_pitch = depth_pitch;
+    begin_load();
+    _depth_cur[_cur] = depth_dev;
+    _depth_pitch[_cur] = depth_pitch;
     preprocess(bgr_dev, bgr_pitch);
 }
 
 void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
-    if (_gx) {
-        check(rgbdslam_frame_preprocess(_ctx, _depth_cur, _depth_pitch, bgr, bgr_pitch, _VMap_dev.p, _NMap_dev.p, _RGB_dev.p, _gx,
-                                        _gpitch, _gy, _gpitch, _n, _m), "frame_preprocess");
-        return;
+    // kernels are enqueued on the context's stream: point it at the load stream for the duration of the load
+    hipStream_t main = ctx_stream(_ctx);
+    if (_load_stream) check(rgbdslam_set_stream(_ctx, _load_stream), "set_stream");
+    int rc;
+    if (_gradients) {
+        rc = rgbdslam_frame_preprocess(_ctx, _depth_cur[_cur], _depth_pitch[_cur], bgr, bgr_pitch, getVMap(), getNMap(), getRGB(), getGx(),
+                                       4 * (size_t)_m, getGy(), 4 * (size_t)_m, _n, _m);
+    } else {
+        rc = rgbdslam_gpu_cpy_char3(_ctx, bgr, bgr_pitch, getRGB(), _n, _m);                                  // Frame.cpp:65
+        if (!rc) rc = rgbdslam_vertex_map_kinect(_ctx, getVMap(), _depth_cur[_cur], _depth_pitch[_cur], _n, _m);   // :68
+        if (!rc) rc = rgbdslam_compute_normal(_ctx, getNMap(), getVMap(), _n, _m, 1);                         // :71
     }
-    check(rgbdslam_gpu_cpy_char3(_ctx, bgr, bgr_pitch, _RGB_dev.p, _n, _m), "gpu_cpy_char3");            // Frame.cpp:65
-    check(rgbdslam_vertex_map_kinect(_ctx, _VMap_dev.p, _depth_cur, _depth_pitch, _n, _m), "VertexMapKinect");  // :68
-    check(rgbdslam_compute_normal(_ctx, _NMap_dev.p, _VMap_dev.p, _n, _m, 1), "ComputeNormal");           // :71
+    if (_load_stream) {
+        check(rgbdslam_set_stream(_ctx, main), "set_stream");
+        if (!rc) hip_check(hipEventRecord(_ready[_cur], _load_stream), "hipEventRecord");
+    }
+    check(rc, "frame preprocess");
 }
 
 // ---- PredictedFrame (D1/Frame.h:188-282) -----------------------------------------------------------
@@ -406,6 +461,15 @@ void Graph::Update(PredictedFrame *frame, float *pose) {
                           frame->_Label_dev, pose, _SizeVBUFF[0], _SizeVBUFF[1], frame->_n, frame->_m, plane_lo, plane_hi),
           "Update_cu");                                                            // Graph.cpp:74
 }
+void Graph::UpdateFromHistory(PredictedFrame *frame, const float *history_entry_dev) {
+    if (_nodes.size() == 0) return;
+    if (!_tables_built) build_tables();
+    _stamp++;
+    check(rgbdslam_update_from_history(_ctx, history_entry_dev, (uint16_t **)_BumpTab.p, (uint8_t **)_RGBTab.p, (uint8_t **)_MaskTab.p,
+                                       (float **)_ParamTab.p, (uint64_t **)_ClaimTab.p, _stamp, frame->getVMap(), frame->getRGB(),
+                                       frame->_Mask_dev, frame->_Label_dev, _SizeVBUFF[0], _SizeVBUFF[1], frame->_n, frame->_m, plane_lo,
+                                       plane_hi), "Update_cu (history)");
+}
 void Graph::UpdateTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb) {
     if (_nodes.size() == 0) return;
     if (!_tables_built) build_tables();
@@ -447,15 +511,25 @@ RG::RG(int device, void *stream, int n, int m, const float *Calib, int lvl, floa
     hip_check(hipMemcpy(_pb_dev, _pb_host, sizeof(rgbdslam_pose_block), hipMemcpyHostToDevice), "pose block init");
     _history_dev.alloc(16 * (size_t)HISTORY_CAP);
     hip_check(hipHostMalloc((void **)&_history_host, 16 * (size_t)HISTORY_CAP * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
-    _frame->AttachGradients(_Gx.p, _Gy.p, 4 * (size_t)m);
+    _frame->EnableGradients(true);
+    hip_check(hipStreamCreateWithFlags(&_load_stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&_update_stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreateWithFlags(&_ev_merged, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&_ev_updated, hipEventDisableTiming), "hipEventCreate");
 }
 
 RG::~RG() {
     if (_ctx) (void)rgbdslam_synchronize(_ctx);
+    if (_load_stream) { (void)hipStreamSynchronize(_load_stream); }
+    if (_update_stream) { (void)hipStreamSynchronize(_update_stream); }
     delete _dataset;
     delete _graph;
     delete _predicted_frame;
     delete _frame;
+    if (_load_stream) (void)hipStreamDestroy(_load_stream);
+    if (_update_stream) (void)hipStreamDestroy(_update_stream);
+    if (_ev_merged) (void)hipEventDestroy(_ev_merged);
+    if (_ev_updated) (void)hipEventDestroy(_ev_updated);
     if (_pinned) (void)hipHostFree(_pinned);
     if (_pb_dev) (void)hipFree(_pb_dev);
     if (_pb_host) (void)hipHostFree(_pb_host);
@@ -466,12 +540,21 @@ RG::~RG() {
     if (_ctx) (void)rgbdslam_destroy(_ctx);
 }
 
+// before the first frame: the fused pipeline loads through the auxiliary stream into alternating buffer sets
+void RG::configure_streams() {
+    const char *e = getenv("RGBDSLAM_OVERLAP_MODE");
+    if (e) _overlap_mode = atoi(e);
+    if (_count == 1 && fused && overlap && (_overlap_mode & 1) && !_frame->load_stream()) _frame->AttachLoadStream(_load_stream);
+}
+
 bool RG::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
+    configure_streams();
     _frame->LoadFrame(depth_host, bgr_host);                                        // RG.cpp:141
     _count++;                                                                       // RG.cpp:144
     return true;
 }
 bool RG::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    configure_streams();
     _frame->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
     _count++;
     return true;
@@ -496,6 +579,7 @@ bool RG::LoadFrame() {
     }
     std::string filename_depth, filename_color;
     _dataset->frame_files(_count, &filename_depth, &filename_color);                // RG.cpp:105-139
+    configure_streams();
     _frame->LoadFrame(filename_depth, filename_color);                              // RG.cpp:141
     _traj_count.push_back(_count);
     _count++;                                                                       // RG.cpp:144
@@ -528,7 +612,7 @@ void RG::SaveTrajectory(const char *filename) {
 
 void RG::SaveModel(const char *dir, int indx) {
     if (fused) Sync();
-    else check(rgbdslam_synchronize(_ctx), "synchronize");
+    SyncAll();
     const int N = _graph->_SizeVBUFF[0], M = _graph->_SizeVBUFF[1];
     const size_t C = (size_t)N * M;
     std::vector<PlanarPatch> nodes;
@@ -563,7 +647,8 @@ bool RG::AlignFrameGaussNewton() {
     size_t pitch = 4 * (size_t)m;
     hipStream_t s = ctx_stream(_ctx);
     // gpu_cpy + 2 x cv::gpu::Sobel, fused (RG.cpp:807-810); already done by frame_preprocess when attached
-    if (!_frame->has_gradients()) check(rgbdslam_intensity_sobel(_ctx, _frame->getRGB(), nullptr, 0, _Gx.p, pitch, _Gy.p, pitch, n, m), "intensity_sobel");
+    float *Gx = _frame->has_gradients() ? _frame->getGx() : _Gx.p, *Gy = _frame->has_gradients() ? _frame->getGy() : _Gy.p;
+    if (!_frame->has_gradients()) check(rgbdslam_intensity_sobel(_ctx, _frame->getRGB(), nullptr, 0, Gx, pitch, Gy, pitch, n, m), "intensity_sobel");
     float *VMap_prev = _predicted_frame->getVMap(), *NMap_prev = _predicted_frame->getNMap();
     float *VMap = _frame->getVMap(), *NMap = _frame->getNMap();
 
@@ -573,7 +658,7 @@ bool RG::AlignFrameGaussNewton() {
         memcpy(ps, _poseR.a, 36); memcpy(ps + 9, _poset.v, 12); memcpy(ps + 12, _poseRPrev.a, 36); memcpy(ps + 21, _posetPrev.v, 12);
         hip_check(hipMemcpyAsync(_pose_state_dev.p, ps, 96, hipMemcpyHostToDevice, s), "pose upload");
         rgbdslam_icp_params prm = icp_params();
-        check(rgbdslam_align_gauss_newton(_ctx, &prm, VMap, NMap, _frame->getRGB(), _Gx.p, pitch, _Gy.p, pitch, VMap_prev,
+        check(rgbdslam_align_gauss_newton(_ctx, &prm, VMap, NMap, _frame->getRGB(), Gx, pitch, Gy, pitch, VMap_prev,
                                           NMap_prev, _predicted_frame->getRGB(), n, m, _pose_state_dev.p, _status_dev.p, nullptr),
               "align_gauss_newton");
         hip_check(hipMemcpyAsync(ps, _pose_state_dev.p, 48, hipMemcpyDeviceToHost, s), "pose download");
@@ -603,8 +688,8 @@ bool RG::AlignFrameGaussNewton() {
             tcurr = Rcurr_inv * _posetPrev + tcurr_inv;
             hip_check(hipMemcpyAsync(_Rcurr_dev.p, Rcurr.a, 36, hipMemcpyHostToDevice, s), "Rcurr");
             hip_check(hipMemcpyAsync(_tcurr_dev.p, tcurr.v, 12, hipMemcpyHostToDevice, s), "tcurr");
-            check(rgbdslam_estimate_system_gauss_newton(_ctx, _Rcurr_dev.p, _tcurr_dev.p, VMap, NMap, _frame->getRGB(), _Gx.p,
-                                                        pitch, _Gy.p, pitch, VMap_prev, NMap_prev, _predicted_frame->getRGB(),
+            check(rgbdslam_estimate_system_gauss_newton(_ctx, _Rcurr_dev.p, _tcurr_dev.p, VMap, NMap, _frame->getRGB(), Gx,
+                                                        pitch, Gy, pitch, VMap_prev, NMap_prev, _predicted_frame->getRGB(),
                                                         _intr_dev.p, _distThres, _angleThres, n, m, A, b, fact, nullptr),
                   "EstimateSystemGaussNewton");                                     // RG.cpp:858
             last_iterations++;
@@ -636,6 +721,8 @@ bool RG::AlignFrameGaussNewton() {
 }
 
 void RG::SetPlanes(const float *equations, const float *centers, int nbPlan) {
+    if (fused && frames_done) Sync();
+    SyncAll();
     _graph->Clear();
     _Equations.assign(equations, equations + 10 * (size_t)nbPlan);
     _Centers.assign(centers, centers + 3 * (size_t)nbPlan);
@@ -729,6 +816,7 @@ void RG::DetectPrimitives(float *pose) {
 
 int RG::DetectPlanes() {                                                              // RG.cpp:154-175
     if (fused) Sync();
+    SyncAll();
     float pose[16];
     pack_pose(_poseR, _poset, pose);
     _graph->Clear();
@@ -794,18 +882,48 @@ int RG::StepAsync() {
     int n = _frame->getN(), m = _frame->getM();
     size_t pitch = 4 * (size_t)m;
     bool first = (_count == 2);
+    hipStream_t main = ctx_stream(_ctx);
+    const bool ovl = _frame->load_stream() != nullptr;
+    const bool ov = fused && overlap && (_overlap_mode & 2);
+    if (ovl) hip_check(hipStreamWaitEvent(main, _frame->ready_event(), 0), "wait for the preprocessed frame");
     if (first) _predicted_frame->ReseedFused(nullptr, 1, _frame);                   // GP-demo.cpp:164-167
     rgbdslam_icp_params prm = icp_params();
-    check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _Gx.p, pitch, _Gy.p, pitch,
+    const int slot = frames_done % HISTORY_CAP;
+    check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _frame->getGx(), pitch, _frame->getGy(), pitch,
                                _predicted_frame->getVMap(), _predicted_frame->getNMap(), _predicted_frame->getRGB(), n, m, _pb_dev,
-                               _history_dev.p, frames_done % HISTORY_CAP), "track_frame");   // GP-demo.cpp:189 + 201-245
+                               _history_dev.p, slot), "track_frame");               // GP-demo.cpp:189 + 201-245
+    // the previous frame's Bump update (other stream) reads the model this frame is about to rewrite
+    if (ov && _update_pending) hip_check(hipStreamWaitEvent(main, _ev_updated, 0), "wait for the previous update");
     // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
     _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
     _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);       // Frame.cpp:242 + 395
     _predicted_frame->MergeFused(_pb_dev, _frame);                                  // GP-demo.cpp:249
-    _graph->UpdateTracked(_predicted_frame, _pb_dev);                               // GP-demo.cpp:260
+    if (ovl) _frame->release(main);                                                 // last reader of this frame's buffer set
+    if (!ov) {
+        _graph->UpdateTracked(_predicted_frame, _pb_dev);                           // GP-demo.cpp:260
+    } else {
+        if (_graph->_nodes.size() != 0) {
+            // Graph::Update on its own stream, posed by this frame's history entry (the pose block is rewritten
+            // by the next frame's tracking, which now runs concurrently)
+            hip_check(hipEventRecord(_ev_merged, main), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(_update_stream, _ev_merged, 0), "hipStreamWaitEvent");
+            check(rgbdslam_set_stream(_ctx, _update_stream), "set_stream");
+            try { _graph->UpdateFromHistory(_predicted_frame, _history_dev.p + 16 * (size_t)slot); }
+            catch (...) { (void)rgbdslam_set_stream(_ctx, main); throw; }
+            check(rgbdslam_set_stream(_ctx, main), "set_stream");
+            hip_check(hipEventRecord(_ev_updated, _update_stream), "hipEventRecord");
+            _update_pending = true;
+        }
+    }
     frames_done++;
     return first ? 2 : 1;
+}
+
+void RG::SyncAll() {
+    if (_load_stream) hip_check(hipStreamSynchronize(_load_stream), "sync load stream");
+    check(rgbdslam_synchronize(_ctx), "synchronize");
+    if (_update_stream) hip_check(hipStreamSynchronize(_update_stream), "sync update stream");
+    _update_pending = false;
 }
 
 int RG::Sync() {
@@ -821,6 +939,7 @@ int RG::Sync() {
         f += cnt;
     }
     hip_check(hipStreamSynchronize(s), "sync");
+    if (_update_pending) { hip_check(hipStreamSynchronize(_update_stream), "sync update stream"); _update_pending = false; }
     _history_synced = hi;
     memcpy(_poseR.a, _pb_host->pose_state, 36); memcpy(_poset.v, _pb_host->pose_state + 9, 12);
     memcpy(_poseRPrev.a, _pb_host->pose_state + 12, 36); memcpy(_posetPrev.v, _pb_host->pose_state + 21, 12);
@@ -914,7 +1033,7 @@ int slamhost_rg_set_fused(void *rg, int on) {
     RG *r = (RG *)rg;
     if (r->_count != 1) return RGBDSLAM_E_STATE;               // choose before the first frame
     r->fused = on != 0;
-    if (!r->fused) r->_frame->AttachGradients(nullptr, nullptr, 0);
+    r->_frame->EnableGradients(r->fused);
     return 0;
 }
 // poses of frames [first, first+count) as 16 floats each: poseR(9) poset(3) tracked iterations level_iters 0
@@ -986,7 +1105,15 @@ int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, 
 }
 int slamhost_rg_synchronize(void *rg) {
     if (!rg) return RGBDSLAM_E_ARG;
-    return rgbdslam_synchronize(((RG *)rg)->ctx());
+    FACADE_TRY(((RG *)rg)->SyncAll());
+    return 0;
+}
+// fused pipeline: 1 = preprocessing of the next frame and the Bump update run on auxiliary streams (default 0)
+int slamhost_rg_set_overlap(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    if (((RG *)rg)->_count != 1) return RGBDSLAM_E_STATE;
+    ((RG *)rg)->overlap = on != 0;
+    return 0;
 }
 int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {
     if (!rg || !R9_cm || !t3) return RGBDSLAM_E_ARG;

@@ -75,38 +75,56 @@ public:
     virtual ~InputFrame() {}
     int getN() const { return _n; }
     int getM() const { return _m; }
-    float *getVMap() { return _VMap_dev.p; }
-    float *getNMap() { return _NMap_dev.p; }
-    float *getRGB() { return _RGB_dev.p; }
+    float *getVMap() { return _VMap_dev[_cur].p; }
+    float *getNMap() { return _NMap_dev[_cur].p; }
+    float *getRGB() { return _RGB_dev[_cur].p; }
     bool _offline = true;
 protected:
     rgbdslam_ctx *_ctx;
     int _n, _m;
-    DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev;
+    // two buffer sets: with a load stream attached (fused pipeline) the next frame is preprocessed into the
+    // other set while the current one is still being tracked and merged; otherwise only set 0 is used
+    int _cur = 0;
+    DevBuf<float> _VMap_dev[2], _NMap_dev[2], _RGB_dev[2];
 };
 
 class OffLineFrame : public InputFrame {
 public:
     OffLineFrame(rgbdslam_ctx *ctx, int n, int m);
+    ~OffLineFrame();
     // D1/Frame.cpp:43-77 with the cv::imread + GpuMat::upload pair replaced by the caller's
     // decoded images: host buffers (uploaded here) or device-resident ones (used in place).
     void LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);
     void LoadFrame(const std::string &filename_depth, const std::string &filename_color);   // Frame.cpp:43-77 (image files)
     void LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
-    // fused pipeline: when gradient buffers are attached, LoadFrame* runs rgbdslam_frame_preprocess
-    // (one kernel for Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
-    void AttachGradients(float *gx, float *gy, size_t pitch) { _gx = gx; _gy = gy; _gpitch = pitch; }
-    bool has_gradients() const { return _gx != nullptr; }
-    const uint16_t *depth() const { return _depth_cur; }
-    size_t depth_pitch() const { return _depth_pitch; }
+    // fused pipeline: with gradients enabled, LoadFrame* runs rgbdslam_frame_preprocess (one kernel for
+    // Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
+    void EnableGradients(bool on);
+    bool has_gradients() const { return _gradients; }
+    float *getGx() { return _Gx[_cur].p; }
+    float *getGy() { return _Gy[_cur].p; }
+    const uint16_t *depth() const { return _depth_cur[_cur]; }
+    size_t depth_pitch() const { return _depth_pitch[_cur]; }
+    // Overlap: loads go to `load_stream` and alternate between the two buffer sets.  ready_event() = the current
+    // set is preprocessed (the consumer stream waits on it); release(consumer) = the consumer's work enqueued
+    // so far is the last that reads the current set (the load that next reuses the set waits on it).
+    void AttachLoadStream(hipStream_t load_stream);
+    hipStream_t load_stream() const { return _load_stream; }
+    hipEvent_t ready_event() const { return _ready[_cur]; }
+    void release(hipStream_t consumer);
 private:
+    void begin_load();
     void preprocess(const uint8_t *bgr, size_t bgr_pitch);
-    DevBuf<uint16_t> _depth_dev_test;
-    DevBuf<uint8_t> _color_dev_test;
-    const uint16_t *_depth_cur = nullptr;
-    size_t _depth_pitch = 0;
-    float *_gx = nullptr, *_gy = nullptr;
-    size_t _gpitch = 0;
+    DevBuf<uint16_t> _depth_dev_test[2];
+    DevBuf<uint8_t> _color_dev_test[2];
+    DevBuf<float> _Gx[2], _Gy[2];
+    const uint16_t *_depth_cur[2] = {nullptr, nullptr};
+    size_t _depth_pitch[2] = {0, 0};
+    bool _gradients = false;
+    hipStream_t _load_stream = nullptr;
+    hipEvent_t _ready[2] = {nullptr, nullptr}, _free[2] = {nullptr, nullptr};
+    bool _free_recorded[2] = {false, false};
+    bool _loaded_once = false;
 };
 
 // ---- D1/Frame.h:188-282 -----------------------------------------------------------------------
@@ -165,6 +183,7 @@ public:
     bool AddPrimitive(Primitive *Prim);                           // Graph.h:100-116
     void Update(PredictedFrame *frame, float *pose);              // Graph.cpp:50-95
     void UpdateTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb);   // same, pose from the device block
+    void UpdateFromHistory(PredictedFrame *frame, const float *history_entry_dev);   // same, pose from the frame's history entry
     void Clear();
     std::vector<Primitive *> _nodes;
     int _SizeVBUFF[2];
@@ -219,6 +238,12 @@ public:
     int StepAsync();
     int Sync();                                                    // -> last frame's status: 1 tracked / 0 lost
     bool fused = true;
+    // fused pipeline only, opt-in: frame k+1's preprocessing and frame k's Bump update run on two auxiliary
+    // streams beside the tracking of frame k+1.  Measured SLOWER than the single stream at 640x480 (4260 vs
+    // 4610 frames/s: the six cross-stream event operations per frame cost more than the 24 us of kernels they
+    // take off the critical path), hence off by default.
+    bool overlap = false;
+    void SyncAll();                                                // main + auxiliary streams
     static const int HISTORY_CAP = 8192;                           // per-frame pose ring (16 floats each)
     int frames_done = 0;
     long tracked_total = 0;                                        // frames tracked so far (as of the last Sync)
@@ -243,6 +268,10 @@ private:
     rgbdslam_ctx *_ctx;
     float _calib[11];
     DevBuf<float> _intr_dev, _Rcurr_dev, _tcurr_dev, _img1, _Gx, _Gy, _pose_state_dev, _trace_dev;
+    hipStream_t _load_stream = nullptr, _update_stream = nullptr;
+    hipEvent_t _ev_merged = nullptr, _ev_updated = nullptr;
+    bool _update_pending = false;
+    int _overlap_mode = 3;   // bit 0: loads on the load stream, bit 1: Bump update on the update stream
     DevBuf<int32_t> _status_dev;
     float *_pinned = nullptr;   // 24 floats pose state + 4 ints status
     rgbdslam_pose_block *_pb_dev = nullptr, *_pb_host = nullptr;   // device block + pinned mirror
@@ -255,6 +284,7 @@ private:
     std::vector<Mat3> _traj_R;                                     // unfused path: poses pushed by Step()
     std::vector<Vec3> _traj_t;
     rgbdslam_icp_params icp_params() const;
+    void configure_streams();
 };
 
 }  // namespace slam

@@ -21,13 +21,14 @@ def same(a, b, what):
     assert ok.all(), "%s: mismatch at %d of %d elements" % (what, (~ok).sum(), ok.size)
 
 
-def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True, index_buffer=False, noise=0.0, fused=True):
+def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True, index_buffer=False, noise=0.0, fused=True, overlap=False):
     calib = synth.calib_for(n, m)
     seq = synth.sequence(frames, n, m, calib, noise_sigma=noise)
     eq, centers = synth.plane_equations()
     ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
     rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
     rg.set_fused(fused)
+    rg.set_overlap(overlap)
     rg.set_device_loop(device_loop)
     rg.set_index_buffer(index_buffer)
     statuses = []
@@ -70,6 +71,11 @@ def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True,
 @pytest.mark.parametrize("fused", [True, False])
 def test_loop_small(pkg, orc, synth, fused):
     run_pair(pkg, orc, synth, 120, 160, frames=6, N_prim=512, planes_at=2, fused=fused)
+
+
+def test_loop_multi_stream_overlap(pkg, orc, synth):
+    """Opt-in stream overlap (loads and Bump updates on auxiliary streams, event-ordered): same bits."""
+    run_pair(pkg, orc, synth, 120, 160, frames=8, N_prim=512, planes_at=2, overlap=True, noise=0.001)
 
 
 def test_loop_odd_size_fused(pkg, orc, synth):
@@ -149,7 +155,8 @@ def test_hip_path_reproduces_golden_fixture(pkg):
     rg.close()
 
 
-def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth, overlap):
     """run_device_sequence enqueues every frame without a host sync (pose history on the device);
     the per-frame poses and the final model must equal the oracle's frame-by-frame loop, including
     a tracking loss in the middle of the sequence."""
@@ -161,6 +168,7 @@ def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth):
     eq, centers = synth.plane_equations()
     ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
     rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg.set_overlap(overlap)
     ref.step(*seq[0]); rg.load_frame(*seq[0]); rg.step()
     ref.set_planes(eq, centers); rg.set_planes(eq, centers)
     want = []
