@@ -68,7 +68,11 @@ extern "C" int rgbdslam_set_pose_matrix(rgbdslam_ctx *ctx, const float *pose16) 
 
 // ---- instrumentation -----------------------------------------------------------------------------
 bool prof_begin(rgbdslam_ctx *ctx, const char *kname) {
-    if (strcmp(ctx->prof_name, kname) != 0) return false;
+    // exact match, or -- for a requested name without template arguments -- every instantiation of that kernel
+    if (strcmp(ctx->prof_name, kname) != 0) {
+        size_t len = strlen(ctx->prof_name);
+        if (strchr(ctx->prof_name, '<') || strncmp(ctx->prof_name, kname, len) != 0 || kname[len] != '<') return false;
+    }
     if (ctx->prof_n == ctx->prof_cap) {
         int cap = ctx->prof_cap ? 2 * ctx->prof_cap : 1024;
         hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * cap);

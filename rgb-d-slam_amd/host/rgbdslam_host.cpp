@@ -1080,6 +1080,13 @@ int slamhost_rg_step(void *rg, int *status) {
     if (status) *status = st;
     return 0;
 }
+// fused pipeline: enqueue one display() pass without waiting for it (poses via slamhost_rg_history / _synchronize)
+int slamhost_rg_step_async(void *rg) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    if (!((RG *)rg)->fused) return RGBDSLAM_E_STATE;
+    FACADE_TRY(((RG *)rg)->StepAsync());
+    return 0;
+}
 // Runs `count` display() passes over device-resident frames (depth_dev[k], bgr_dev[k]); returns
 // the number of tracked frames in *tracked.  One host sync per frame (the pose read), no other.
 int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, const uint8_t *const *bgr_dev, int count,
