@@ -14,14 +14,8 @@ __device__ __forceinline__ unsigned long long claim_key(uint32_t stamp, bool wri
 
 struct UpdCell { int L, cell; float sa, sb, err; };
 
-// geometry of D1/Primitive.cu:278-307
-__device__ __forceinline__ bool update_cell(const float *__restrict__ VMap, const uint8_t *__restrict__ Label,
-                                            const PoseV &P, float *const *__restrict__ ParamTab, size_t idx, int N_prim,
-                                            int M_prim, int plane_lo, int plane_hi, UpdCell &o) {
-    int L = (int)Label[idx] - 1;
-    if (L < 0 || L < plane_lo || L >= plane_hi) return false;
-    const float *Q = ParamTab[L];
-    F3 p = xf_point(P.v, ld3(VMap, idx));
+// geometry of D1/Primitive.cu:278-307 for a pixel whose plane parameters Q are known
+__device__ __forceinline__ bool update_cell(const F3 &p, const float *__restrict__ Q, int N_prim, int M_prim, UpdCell &o) {
     o.err = ((p.x * Q[0] + p.y * Q[1]) + p.z * Q[2]) - Q[3];
     float a = (p.x * Q[8] + p.y * Q[9]) + p.z * Q[10];
     float b = (p.x * Q[11] + p.y * Q[12]) + p.z * Q[13];
@@ -29,10 +23,14 @@ __device__ __forceinline__ bool update_cell(const float *__restrict__ VMap, cons
     b = (float)((double)((b - Q[7]) * Q[5]) / 2.0);
     int ii = f2i_rd(a), jj = f2i_rd(b);
     if (ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0) return false;
-    o.L = L; o.cell = ii * M_prim + jj; o.sa = a - (float)ii; o.sb = b - (float)jj;
+    o.cell = ii * M_prim + jj; o.sa = a - (float)ii; o.sb = b - (float)jj;
     return true;
 }
 
+// The per-pixel work is a chain of dependent gathers (label -> plane tables -> cell mask -> claim word -> stores).
+// A wavefront is 64 consecutive pixels of one image row and almost always sees ONE label: then the plane's table
+// entries and its 14 parameters are fetched once per wave through a wave-uniform address (scalar loads) instead of
+// once per lane, which takes two vector-memory round trips out of the chain.
 template <bool APPLY>
 __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *__restrict__ RGBTab,
                          uint8_t *const *__restrict__ MaskTab, float *const *__restrict__ ParamTab,
@@ -53,21 +51,47 @@ __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *
         P.v[12] = hist[9]; P.v[13] = hist[10]; P.v[14] = hist[11]; P.v[15] = 1.0f;
     }
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
-    size_t idx = (size_t)i * m + j;
+    const bool in = i < n && j < m;
+    const size_t idx = in ? (size_t)i * m + j : 0;
+    int L = in ? (int)Label[idx] - 1 : -1;
+    const bool valid = L >= 0 && L >= plane_lo && L < plane_hi;
+    const unsigned long long vmask = __ballot(valid);
+    if (!vmask) return;
+    const int L0 = __builtin_amdgcn_readfirstlane(__shfl(L, (int)__builtin_ctzll(vmask)));
+    const bool one_plane = __ballot(valid && L != L0) == 0ull;
+    if (!valid) return;
+    const uint8_t mc = Mask[idx];
+    const F3 p = xf_point(P.v, ld3(VMap, idx));
     UpdCell u;
-    if (!update_cell(VMap, Label, P, ParamTab, idx, N_prim, M_prim, plane_lo, plane_hi, u)) return;
-    uint8_t mc = Mask[idx];
-    uint8_t *cellmask = MaskTab[u.L] + u.cell;
-    uint8_t mref = *cellmask;
+    uint8_t *maskb;
+    unsigned long long *claimb;
+    uint16_t *bumpb;
+    uint8_t *rgbb;
+    if (one_plane) {                                  // wave-uniform plane: table entries and parameters via uniform addresses
+        const float *Q = ParamTab[L0];
+        float q[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = Q[k];
+        maskb = MaskTab[L0]; claimb = ClaimTab[L0]; bumpb = BumpTab[L0]; rgbb = RGBTab[L0];
+        if (!update_cell(p, q, N_prim, M_prim, u)) return;
+        u.L = L0;
+    } else {
+        if (!update_cell(p, ParamTab[L], N_prim, M_prim, u)) return;
+        u.L = L;
+        maskb = MaskTab[L]; claimb = ClaimTab[L]; bumpb = BumpTab[L]; rgbb = RGBTab[L];
+    }
+    uint8_t *cellmask = maskb + u.cell;
+    unsigned long long *slot = claimb + u.cell;
+    const uint8_t mref = *cellmask;
+    unsigned long long owner = 0ull;
+    if (APPLY) owner = *slot;                         // independent of the mask test: both gathers are in flight together
     bool erode = (mc < 10 && mref != 1);                                      // Primitive.cu:313
     if (!erode && !(mc > mref)) return;                                       // Primitive.cu:341
     unsigned long long key = claim_key(stamp, !erode, erode ? (uint8_t)0 : mc, (uint32_t)idx);
-    unsigned long long *slot = ClaimTab[u.L] + u.cell;
     if (!APPLY) { atomicMax(slot, key); return; }
-    if (*slot != key) return;
-    uint16_t *B = BumpTab[u.L] + 3 * (size_t)u.cell;
-    uint8_t *C = RGBTab[u.L] + 3 * (size_t)u.cell;
+    if (owner != key) return;
+    uint16_t *B = bumpb + 3 * (size_t)u.cell;
+    uint8_t *C = rgbb + 3 * (size_t)u.cell;
     if (erode) {
         if (mref > 11) { *cellmask = (uint8_t)(mref - 1); }
         else { *cellmask = 10; B[0] = 0; B[1] = 0; B[2] = 0; C[0] = 0; C[1] = 0; C[2] = 0; }
