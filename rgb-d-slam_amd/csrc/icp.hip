@@ -68,7 +68,8 @@ __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr
     const float4 cp = mp.cp;
     const float d0 = pr.d0, d1 = pr.d1, d2 = pr.d2, n0 = pr.n0, n1 = pr.n1, n2 = pr.n2, az = pr.az;
     const size_t pidx = pr.pidx;
-    float i_prev = (float)((double)((cp.x + cp.y) + cp.z) / 3.0);
+    // (float)((double)x / 3.0) == x / 3.0f for float x: double rounding is innocuous for division (53 >= 2*24 + 2)
+    float i_prev = ((cp.x + cp.y) + cp.z) / 3.0f;                               // ICP.cu:100
 
     F3 nc = cu.nc;
     if (is_zero3(nc)) return false;
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr
     if (ang > angleThres) return false;
 
     F3 cc = cu.cc;
-    float i_curr = (float)((double)((cc.x + cc.y) + cc.z) / 3.0);
+    float i_curr = ((cc.x + cc.y) + cc.z) / 3.0f;
     float g0 = (float)((double)cu.gx / 8.0);
     float g1 = (float)((double)cu.gy / 8.0);
     float g2 = i_curr - i_prev;
