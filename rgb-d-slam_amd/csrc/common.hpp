@@ -44,12 +44,18 @@ struct rgbdslam_ctx {
     const char *prof_name;
     hipEvent_t *prof_ev;   // 2 * prof_cap events
     int prof_cap, prof_n;
+    int prof_launches;     // launches covered by the recorded event pairs
+    bool prof_in_group;    // inside prof_group_begin/end: launches are counted, the group carries the one event pair
 };
 
 // Launch on the context's stream; when the kernel's name is the one being profiled, bracket the
 // launch with a HIP event pair recorded on that same stream.
 bool prof_begin(rgbdslam_ctx *ctx, const char *kname);
 void prof_end(rgbdslam_ctx *ctx);
+// one event pair around a run of back-to-back launches of `kname` (their average then includes the real
+// launch-to-launch behaviour instead of one marker round trip per launch)
+bool prof_group_begin(rgbdslam_ctx *ctx, const char *kname);
+void prof_group_end(rgbdslam_ctx *ctx);
 #define KLAUNCH(ctx, kern, grid, block, ...)                                         \
     do {                                                                             \
         bool _prof = (ctx)->prof_name && prof_begin((ctx), #kern);                   \

@@ -20,7 +20,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->have_calib = false;
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->buf_dev = nullptr; c->ticket_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr;
-    c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0;
+    c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_launches = 0; c->prof_in_group = false;
     *out = c;
     return 0;
 }
@@ -67,12 +67,13 @@ extern "C" int rgbdslam_set_pose_matrix(rgbdslam_ctx *ctx, const float *pose16) 
 }
 
 // ---- instrumentation -----------------------------------------------------------------------------
-bool prof_begin(rgbdslam_ctx *ctx, const char *kname) {
+static bool prof_matches(const rgbdslam_ctx *ctx, const char *kname) {
     // exact match, or -- for a requested name without template arguments -- every instantiation of that kernel
-    if (strcmp(ctx->prof_name, kname) != 0) {
-        size_t len = strlen(ctx->prof_name);
-        if (strchr(ctx->prof_name, '<') || strncmp(ctx->prof_name, kname, len) != 0 || kname[len] != '<') return false;
-    }
+    if (strcmp(ctx->prof_name, kname) == 0) return true;
+    size_t len = strlen(ctx->prof_name);
+    return !strchr(ctx->prof_name, '<') && strncmp(ctx->prof_name, kname, len) == 0 && kname[len] == '<';
+}
+static bool prof_record_first(rgbdslam_ctx *ctx) {
     if (ctx->prof_n == ctx->prof_cap) {
         int cap = ctx->prof_cap ? 2 * ctx->prof_cap : 1024;
         hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * cap);
@@ -84,9 +85,25 @@ bool prof_begin(rgbdslam_ctx *ctx, const char *kname) {
     }
     return hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream) == hipSuccess;
 }
+bool prof_begin(rgbdslam_ctx *ctx, const char *kname) {
+    if (!prof_matches(ctx, kname)) return false;
+    if (ctx->prof_in_group) { ctx->prof_launches++; return false; }
+    if (!prof_record_first(ctx)) return false;
+    ctx->prof_launches++;
+    return true;
+}
 void prof_end(rgbdslam_ctx *ctx) {
     (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream);
     ctx->prof_n++;
+}
+bool prof_group_begin(rgbdslam_ctx *ctx, const char *kname) {
+    if (!ctx->prof_name || ctx->prof_in_group || !prof_matches(ctx, kname) || !prof_record_first(ctx)) return false;
+    ctx->prof_in_group = true;
+    return true;
+}
+void prof_group_end(rgbdslam_ctx *ctx) {
+    ctx->prof_in_group = false;
+    prof_end(ctx);
 }
 
 extern "C" int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_name) {
@@ -94,6 +111,8 @@ extern "C" int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_nam
     free((void *)ctx->prof_name);
     ctx->prof_name = kernel_name ? strdup(kernel_name) : nullptr;
     ctx->prof_n = 0;
+    ctx->prof_launches = 0;
+    ctx->prof_in_group = false;
     return 0;
 }
 
@@ -107,8 +126,9 @@ extern "C" int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *l
         tot += ms;
     }
     *total_ms = tot;
-    *launches = ctx->prof_n;
+    *launches = ctx->prof_launches;
     ctx->prof_n = 0;
+    ctx->prof_launches = 0;
     return 0;
 }
 

@@ -807,6 +807,8 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
     IcpEndArgs end = {pose_state_dev, status_dev, pose_block, history, frame_index};
     if (!ride) KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
     int fact = 1 << (prm->lvl - 1);                            // RG.cpp:832
+    // instrumentation: the loop's launches are back to back, so one event pair brackets all of them
+    const bool prof_group = prof_group_begin(ctx, "k_icp_iter");
     for (int lvl = prm->lvl - 1; lvl > -1; lvl--) {
         int n_it = prm->max_iter[lvl] + 2;                     // iter = 0 .. max_iter+1 (RG.cpp:889)
         for (int iter = 0; iter < n_it; iter++) {
@@ -814,10 +816,11 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
             rc = launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, fact, 0, 1 << 30,
                              ctx->outbuf_dev, nullptr, st, pose_state_dev, 1, lvl, iter, prm->max_iter[lvl],
                              prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev, first, last, ride ? &end : nullptr);
-            if (rc) return rc;
+            if (rc) { if (prof_group) prof_group_end(ctx); return rc; }
         }
         fact /= 2;
     }
+    if (prof_group) prof_group_end(ctx);
     if (!ride) KLAUNCH(ctx, k_icp_end, dim3(1), dim3(64), st, pose_state_dev, status_dev, pose_block, history, frame_index);
     HIP_TRY(hipGetLastError());
     return 0;
