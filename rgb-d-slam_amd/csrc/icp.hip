@@ -214,7 +214,7 @@ struct IcpIterArgs {
 struct IcpEndArgs { float *pose_state; int32_t *status; rgbdslam_pose_block *pb; float *history; int frame_index; };
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
-                                               const IcpEndArgs *end);
+                                               bool with_end, IcpEndArgs end);
 __device__ __forceinline__ void icp_begin_step(IcpState *st, const float *pose_state, const float *intr4);
 __device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArgs &e);
 
@@ -346,17 +346,21 @@ void k_icp_iter(IcpIterArgs a) {
     // lane holds (t = lane + 64q), offsets 32..1 are lane shuffles.  Chains beyond nblk hold 0.
     // Wave w owns terms w, w+W, w+2W...; all of its loads are issued before the first add so the
     // tail costs one memory round trip, not one per term.
+    // The loads are unconditional (the buffer always holds 27 x 512 floats; out-of-range terms re-read term 26) and
+    // the unused values are replaced by 0 afterwards: predicated loads made the compiler wait for memory between them.
     float x[ICP_TAIL_TERMS][8];
 #pragma unroll
     for (int u = 0; u < ICP_TAIL_TERMS; u++) {
-        int term = wave + ICP_MAX_WAVES * u;
+        const int term = min(wave + ICP_MAX_WAVES * u, 26);
 #pragma unroll
-        for (int qd = 0; qd < 8; qd++) {
-            int tt = lane + 64 * qd;
-            x[u][qd] = (term < 27 && tt < a.nchain)
-                           ? __hip_atomic_load(a.chains + term * ICP_CHAINS + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                           : 0.0f;
-        }
+        for (int qd = 0; qd < 8; qd++)
+            x[u][qd] = __hip_atomic_load(a.chains + term * ICP_CHAINS + lane + 64 * qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.nchain < ICP_CHAINS) {
+#pragma unroll
+        for (int u = 0; u < ICP_TAIL_TERMS; u++)
+#pragma unroll
+            for (int qd = 0; qd < 8; qd++) x[u][qd] = (lane + 64 * qd < a.nchain) ? x[u][qd] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < ICP_TAIL_TERMS; u++) {
@@ -379,7 +383,7 @@ void k_icp_iter(IcpIterArgs a) {
     if (a.do_solve) {
         IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
         icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh,
-                       a.final_launch ? &e : nullptr);
+                       a.final_launch != 0, e);        // by value: a pointer to the local would put it in scratch memory
     }
     if (a.timing && threadIdx.x == 0) {
         a.timing[1] = ts0; a.timing[2] = ts1; a.timing[3] = ts2; a.timing[4] = ts3; a.timing[5] = ts4; a.timing[6] = wall_clock64();
@@ -389,40 +393,50 @@ void k_icp_iter(IcpIterArgs a) {
 // ---- device-side 6x6 solve and pose update (D1/RG.cpp:851-901) ---------------------------------
 #define M3(a, r, c) (a)[(c) * 3 + (r)]
 
-__device__ void d_mat3_mul(const float *a, const float *b, float *o) {
+__device__ __forceinline__ void d_mat3_mul(const float *a, const float *b, float *o) {
     float r[9];
+#pragma unroll
     for (int c = 0; c < 3; c++)
+#pragma unroll
         for (int i = 0; i < 3; i++)
             r[c * 3 + i] = (M3(a, i, 0) * M3(b, 0, c) + M3(a, i, 1) * M3(b, 1, c)) + M3(a, i, 2) * M3(b, 2, c);
+#pragma unroll
     for (int k = 0; k < 9; k++) o[k] = r[k];
 }
-__device__ void d_mat3_vec(const float *a, const float *v, float *o) {
+__device__ __forceinline__ void d_mat3_vec(const float *a, const float *v, float *o) {
     float r[3];
+#pragma unroll
     for (int i = 0; i < 3; i++) r[i] = (M3(a, i, 0) * v[0] + M3(a, i, 1) * v[1]) + M3(a, i, 2) * v[2];
     o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
 }
-__device__ void d_inverse3(const float *a, float *o) {
+__device__ __forceinline__ void d_inverse3(const float *a, float *o) {
     float cof[3][3];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
             cof[i][j] = M3(a, i1, j1) * M3(a, i2, j2) - M3(a, i1, j2) * M3(a, i2, j1);
         }
     float det = (cof[0][0] * M3(a, 0, 0) + cof[1][0] * M3(a, 1, 0)) + cof[2][0] * M3(a, 2, 0);
     float invdet = 1.0f / det;
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) M3(o, i, j) = cof[j][i] * invdet;
 }
-__device__ float d_frob_minus_I(const float *a) {
+__device__ __forceinline__ float d_frob_minus_I(const float *a) {
     float s = 0.0f;
+#pragma unroll
     for (int c = 0; c < 3; c++)
+#pragma unroll
         for (int r = 0; r < 3; r++) {
             float v = M3(a, r, c) - (r == c ? 1.0f : 0.0f);
             s = s + v * v;
         }
     return __builtin_sqrtf(s);
 }
-__device__ float d_norm3(const float *v) { return __builtin_sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+__device__ __forceinline__ float d_norm3(const float *v) { return __builtin_sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
 // ---- 6x6 helpers (stand-ins for Eigen's determinant() and llt().solve(), same operation order as
 // the oracle's orc_det6 / orc_llt_solve6) ----------------------------------------------------------
@@ -510,7 +524,7 @@ __device__ __forceinline__ int llt_solve6_reg(const float *sums, float *x) {
 }
 
 // pose_state = poseR(9) poset(3) poseRPrev(9) posetPrev(3)
-__device__ void d_set_rt_curr(IcpState *st, const float *ps) {
+__device__ __forceinline__ void d_set_rt_curr(IcpState *st, const float *ps) {
     float tmp[3];
     d_mat3_mul(st->Rinv, ps + 12, st->Rcurr);                 // RG.cpp:851
     d_mat3_vec(st->Rinv, ps + 21, tmp);                       // RG.cpp:852
@@ -569,7 +583,7 @@ __device__ __forceinline__ void icp_pose_update(IcpState *st, const float *x, co
 
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
-                                               const IcpEndArgs *end) {
+                                               bool with_end, IcpEndArgs end) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float x[6];
     int llt_fail = 0;
@@ -594,7 +608,7 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
     }
     *out = loc;
-    if (end) icp_end_step(&loc, *end);
+    if (with_end) icp_end_step(&loc, end);
 }
 
 // stand-alone solve for the row-sharded path (launch with 128 threads): sums = sum over `parts`
@@ -615,7 +629,7 @@ void k_icp_solve(IcpState *st, const float *__restrict__ gathered, int parts, co
     }
     __syncthreads();
     if (sst.fail || (iter > 0 && sst.cvg)) return;
-    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh, nullptr);
+    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh, false, IcpEndArgs{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
 __device__ __forceinline__ void d_pack_pose(const float *R, const float *t, float *P) {   // GP-demo.cpp:206-211
