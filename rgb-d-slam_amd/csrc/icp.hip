@@ -61,6 +61,14 @@ __device__ __forceinline__ IcpCurrPx icp_gather(const IcpProj &p, const float *_
     return c;
 }
 
+// The consumers of the gathered values sit behind early exits (zero normal, distance, angle); left alone, the
+// compiler sinks each load behind the exit that precedes its first use and the gather becomes three dependent
+// memory round trips.  Passing the values through an empty asm pins all five loads before the first test.
+__device__ __forceinline__ void icp_pin_gather(IcpCurrPx &c) {
+    asm volatile("" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(c.cc.x), "+v"(c.cc.y),
+                 "+v"(c.cc.z), "+v"(c.gx), "+v"(c.gy));
+}
+
 // Returns false -> zero rows.
 __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr, const IcpCurrPx &cu, const float *intr,
                                          float distThres, float angleThres, IcpRow &o, int &proj) {
@@ -292,6 +300,7 @@ void k_icp_iter(IcpIterArgs a) {
             for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
             IcpProj pr = icp_project(mp, sst.Rcurr, sst.tcurr, sst.intr, a.n, a.m);
             IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
+            icp_pin_gather(cu);
             if (inside) {
                 int proj = -1;
                 IcpRow o;
