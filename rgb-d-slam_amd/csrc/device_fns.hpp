@@ -279,20 +279,29 @@ __device__ __forceinline__ uint8_t segment_pixel(const uint8_t *__restrict__ in,
         F3 p = xf_point(P, pl);
         float depth = pl.z;
         const float thresh_depth = 0.003f;
-        int lb = max(0, i - 1), ub = min(n, i + 2), lr = max(0, j - 1), ur = min(m, j + 2);
-        for (int ki = lb; ki < ub && res == 0; ki++)
-            for (int kj = lr; kj < ur; kj++) {
-                size_t nb = (size_t)ki * m + kj;
-                uint8_t l = in[nb];
-                if (l > 0 && __builtin_fabsf(VMap[3 * nb + 2] - depth) < thresh_depth) {
-                    const float *E = Eq + 10 * ((int)l - 1);
-                    float ed = ((p.x * E[0] + p.y * E[1]) + p.z * E[2]) - E[9];
-                    float ea = (q.x * E[0] + q.y * E[1]) + q.z * E[2];
-                    if (__builtin_fabsf(ed) > epsilon || ea < alpha) continue;
-                    res = l;
-                    break;
-                }
+        // The reference scans the 3x3 neighbourhood row by row and stops at the first neighbour that qualifies
+        // (RG.cu:285-311).  All nine labels and depths are fetched first (independent loads, one round trip); the
+        // scan then runs on registers in the same order, so the same neighbour wins.
+        uint8_t lab[9];
+        float dz[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int ki = i - 1 + k / 3, kj = j - 1 + k % 3;
+            bool ok = ki >= 0 && ki < n && kj >= 0 && kj < m;
+            size_t nb = ok ? (size_t)ki * m + kj : idx;
+            lab[k] = ok ? in[nb] : (uint8_t)0;
+            dz[k] = VMap[3 * nb + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint8_t l = lab[k];
+            if (res == 0 && l > 0 && __builtin_fabsf(dz[k] - depth) < thresh_depth) {
+                const float *E = Eq + 10 * ((int)l - 1);
+                float ed = ((p.x * E[0] + p.y * E[1]) + p.z * E[2]) - E[9];
+                float ea = (q.x * E[0] + q.y * E[1]) + q.z * E[2];
+                if (!(__builtin_fabsf(ed) > epsilon || ea < alpha)) res = l;
             }
+        }
     }
     return res;
 }
