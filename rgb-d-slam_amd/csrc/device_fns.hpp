@@ -71,6 +71,12 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
+// Pins loaded values in front of the branches that follow: passed through an empty asm they must all be present
+// there, so the compiler cannot sink each load behind the branch that precedes its first use (which turns a batch
+// of independent loads into a chain of dependent memory round trips).
+__device__ __forceinline__ void pin_loaded(F3 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)); }
+__device__ __forceinline__ void pin_loaded(float4 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+
 // ---- D1/Kernel.cu:440-526 MergeDepthOffKernel: new (.w, mask) of one pixel -------------------------
 // returns the new .w; newmask < 0 = mask unchanged
 __device__ __forceinline__ float merge_pixel(float w_old, uint16_t d, uint8_t mask_old, const CalibV &c, int &newmask) {

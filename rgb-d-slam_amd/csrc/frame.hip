@@ -141,8 +141,9 @@ __global__ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const
     const float *P = pb->P_rel;
     uint32_t q = (uint32_t)(i * (m - 1) + j), id[4];
     quad_vertex_ids(q, nullptr, m, id);
-    F3 v0 = warp_vertex(P, ld3(VMap, id[0])), v1 = warp_vertex(P, ld3(VMap, id[1])), v2 = warp_vertex(P, ld3(VMap, id[2])),
-       v3 = warp_vertex(P, ld3(VMap, id[3]));
+    F3 v0 = ld3(VMap, id[0]), v1 = ld3(VMap, id[1]), v2 = ld3(VMap, id[2]), v3 = ld3(VMap, id[3]);
+    pin_loaded(v0); pin_loaded(v1); pin_loaded(v2); pin_loaded(v3);    // four loads in flight, then the warps
+    v0 = warp_vertex(P, v0); v1 = warp_vertex(P, v1); v2 = warp_vertex(P, v2); v3 = warp_vertex(P, v3);
     if (quad_trimmed(v0, v1, v2, v3, thresh)) return;
     F3 t0[3] = {v0, v1, v2}, t1[3] = {v0, v2, v3};
     ras_draw(zbuf, t0, 2 * q, c, znear, zfar, n, m);
@@ -173,8 +174,14 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
         float4 att[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            vtx[k] = warp_vertex(P, ld3(VMap_in, vid[k]));
+            vtx[k] = ld3(VMap_in, vid[k]);
             att[k] = *(const float4 *)(RGBD_in + 4 * (size_t)vid[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pin_loaded(vtx[k]); pin_loaded(att[k]); }   // six loads in flight, then the warps
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            vtx[k] = warp_vertex(P, vtx[k]);
             att[k].w = depth_attr(vtx[k].z);                       // Kernel.cu:368-371
         }
         tex = ras_shade(vtx, att, c, px, py);
