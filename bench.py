@@ -49,7 +49,7 @@ PER_PX = {"k_frame_preprocess": 2 + 3 + 12 + 12 + 12 + 4 + 4,          # depth u
           "k_predict_resolve": 8 + 12 + 16 + 1 + 1 + 12 + 16 + 1 + 1,  # zbuf, VMap/RGBD/Mask/Label in -> out
           "k_normal_segment": 12 + 12 + 1 + 1,                         # VMap -> NMap, Label in/out
           "k_segment_pass_pb": 12 + 12 + 1 + 1,
-          "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12,         # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap
+          "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12 + 1 + 1 + 8,   # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap; + claim pass: Label, cell mask, claim word
           "k_update<false>": 12 + 1 + 1 + 8, "k_update<true>": 12 + 16 + 1 + 1 + 10}
 
 

@@ -194,6 +194,20 @@ int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bloc
                          const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
                          size_t depth_pitch_bytes, const float *RGB, float *RGBD_out,
                          uint8_t *Mask_out, float *VMap_out, float *NMap_out, int n, int m);
+/* PredictedFrame::Merge + the CLAIM pass of the Graph::Update that follows it in display() (GP-demo.cpp:249-260): the
+ * claim of a pixel needs only its own merged vertex and mask, so it rides on the merge launch.  Follow with
+ * rgbdslam_update_apply_tracked (same stamp, same tables) to finish the update. */
+int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                               const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
+                               size_t depth_pitch_bytes, const float *RGB, float *RGBD_out,
+                               uint8_t *Mask_out, float *VMap_out, float *NMap_out, const uint8_t *Label,
+                               uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp,
+                               int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi);
+int rgbdslam_update_apply_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                                  uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                                  uint64_t **ClaimTab, uint32_t stamp, const float *VMap, const float *RGBD,
+                                  const uint8_t *Mask, const uint8_t *Label, int N_prim, int M_prim, int n,
+                                  int m, int plane_lo, int plane_hi);
 /* Graph::Update (Graph.cpp:50-95) with the pose taken from the block (P_glob) and gated on it. */
 int rgbdslam_update_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
                             uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,

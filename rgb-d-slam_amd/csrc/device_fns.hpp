@@ -353,3 +353,29 @@ __device__ __forceinline__ BumpParam load_param(const float *__restrict__ param)
     for (int k = 0; k < 14; k++) P.p[k] = param[k];
     return P;
 }
+
+// ---- D1/Primitive.cu:267-357 UpdateKernel: claim key and cell geometry (shared by k_update and the merge+claim fusion)
+// Winner rule replacing the data race of UpdateKernel (D1/Primitive.cu:309-349), see DESIGN.md:
+// all threads decide against the SNAPSHOT of the cell mask taken before any write; a gate-passing
+// writer beats an eroder; among writers the highest mask_curr wins, ties go to the lowest frame
+// pixel index; with only eroders on a cell a single erode step is applied.
+// key = stamp(32) | writer(1) | mask_curr(8) | ~idx(23)
+__device__ __forceinline__ unsigned long long claim_key(uint32_t stamp, bool writer, uint8_t mc, uint32_t idx) {
+    uint32_t lo = ((uint32_t)(writer ? 1u : 0u) << 31) | ((uint32_t)mc << 23) | (0x7FFFFFu - idx);
+    return ((unsigned long long)stamp << 32) | lo;
+}
+
+struct UpdCell { int L, cell; float sa, sb, err; };
+
+// geometry of D1/Primitive.cu:278-307 for a pixel whose plane parameters Q are known
+__device__ __forceinline__ bool update_cell(const F3 &p, const float *__restrict__ Q, int N_prim, int M_prim, UpdCell &o) {
+    o.err = ((p.x * Q[0] + p.y * Q[1]) + p.z * Q[2]) - Q[3];
+    float a = (p.x * Q[8] + p.y * Q[9]) + p.z * Q[10];
+    float b = (p.x * Q[11] + p.y * Q[12]) + p.z * Q[13];
+    a = (float)((double)((a - Q[6]) * Q[4]) / 2.0);
+    b = (float)((double)((b - Q[7]) * Q[5]) / 2.0);
+    int ii = f2i_rd(a), jj = f2i_rd(b);
+    if (ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0) return false;
+    o.cell = ii * M_prim + jj; o.sa = a - (float)ii; o.sb = b - (float)jj;
+    return true;
+}

@@ -225,11 +225,33 @@ __global__ void k_segment_pass_pb(const rgbdslam_pose_block *__restrict__ pb, co
 
 // ---- PredictedFrame::Merge (Frame.cpp:300-333): MergeDepthOff + VertexMapGL + ComputeNormal -----------
 // set "in" -> set "out"; the merged vertices of the tile + halo are staged in LDS for the normals.
+// Claim pass of Graph::Update (k_update<false>, D1/Primitive.cu:267-357 under the winner rule of DESIGN.md 4.2) for
+// the pixel that was just merged: it needs only that pixel's new vertex and mask, so it rides on the merge instead
+// of costing a launch of its own.  ParamTab == nullptr: no planes / plain merge.
+struct MergeClaimArgs {
+    float *const *ParamTab;
+    uint8_t *const *MaskTab;
+    unsigned long long *const *ClaimTab;
+    const uint8_t *Label;
+    uint32_t stamp;
+    int N_prim, M_prim, plane_lo, plane_hi;
+};
+__device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const float *P_glob, F3 v, uint8_t mc, size_t idx) {
+    int L = (int)ca.Label[idx] - 1;
+    if (L < 0 || L < ca.plane_lo || L >= ca.plane_hi) return;
+    UpdCell u;
+    if (!update_cell(xf_point(P_glob, v), ca.ParamTab[L], ca.N_prim, ca.M_prim, u)) return;
+    const uint8_t mref = ca.MaskTab[L][u.cell];
+    const bool erode = (mc < 10 && mref != 1);                                // Primitive.cu:313
+    if (!erode && !(mc > mref)) return;                                       // Primitive.cu:341
+    atomicMax(ca.ClaimTab[L] + u.cell, claim_key(ca.stamp, !erode, erode ? (uint8_t)0 : mc, (uint32_t)idx));
+}
+
 __global__ __launch_bounds__(TILE_W * TILE_H)
 void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ RGBD_in,
                    const uint8_t *__restrict__ Mask_in, const uint16_t *__restrict__ depth, size_t dpitch,
                    const float *__restrict__ RGB, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
-                   float *__restrict__ VMap_out, float *__restrict__ NMap_out, CalibV c, int n, int m) {
+                   float *__restrict__ VMap_out, float *__restrict__ NMap_out, CalibV c, MergeClaimArgs ca, int n, int m) {
     if (!pb_tracked(pb)) return;
     __shared__ float sv[HALO_H][HALO_W][3];
     const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
@@ -253,8 +275,10 @@ void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__re
                 F3 col = ld3(RGB, idx);
                 px.x = col.x; px.y = col.y; px.z = col.z; px.w = w;
                 *(float4 *)(RGBD_out + 4 * idx) = px;
-                Mask_out[idx] = (newmask >= 0) ? (uint8_t)newmask : mk;
+                const uint8_t mc = (newmask >= 0) ? (uint8_t)newmask : mk;
+                Mask_out[idx] = mc;
                 st3(VMap_out, idx, v.x, v.y, v.z);
+                if (ca.ParamTab) merge_claim(ca, pb->P_glob, v, mc, idx);
             }
         }
         sv[r][cc][0] = v.x; sv[r][cc][1] = v.y; sv[r][cc][2] = v.z;
@@ -352,8 +376,27 @@ extern "C" int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block
         return RGBDSLAM_E_ARG;
     if (RGBD_in == RGBD_out || Mask_in == Mask_out || n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
     KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out,
-            VMap_out, NMap_out, ctx->calib, n, m);
+            VMap_out, NMap_out, ctx->calib, none, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *RGBD_in,
+                                          const uint8_t *Mask_in, const uint16_t *depth, size_t depth_pitch, const float *RGB,
+                                          float *RGBD_out, uint8_t *Mask_out, float *VMap_out, float *NMap_out,
+                                          const uint8_t *Label, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                          uint32_t stamp, int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi) {
+    if (!ctx || !pose_block_dev || !RGBD_in || !Mask_in || !depth || !RGB || !RGBD_out || !Mask_out || !VMap_out || !NMap_out)
+        return RGBDSLAM_E_ARG;
+    if (!Label || !MaskTab || !ParamTab || !ClaimTab || stamp == 0 || N_prim <= 0 || M_prim <= 0) return RGBDSLAM_E_ARG;
+    if (RGBD_in == RGBD_out || Mask_in == Mask_out || n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;                   // 23-bit pixel index in the claim key
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, Label, stamp, N_prim, M_prim, plane_lo, plane_hi};
+    KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out,
+            VMap_out, NMap_out, ctx->calib, ca, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }

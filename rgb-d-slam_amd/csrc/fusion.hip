@@ -2,31 +2,6 @@
 #include "common.hpp"
 #include "device_fns.hpp"
 
-// Winner rule replacing the data race of UpdateKernel (D1/Primitive.cu:309-349), see DESIGN.md:
-// all threads decide against the SNAPSHOT of the cell mask taken before any write; a gate-passing
-// writer beats an eroder; among writers the highest mask_curr wins, ties go to the lowest frame
-// pixel index; with only eroders on a cell a single erode step is applied.
-// key = stamp(32) | writer(1) | mask_curr(8) | ~idx(23)
-__device__ __forceinline__ unsigned long long claim_key(uint32_t stamp, bool writer, uint8_t mc, uint32_t idx) {
-    uint32_t lo = ((uint32_t)(writer ? 1u : 0u) << 31) | ((uint32_t)mc << 23) | (0x7FFFFFu - idx);
-    return ((unsigned long long)stamp << 32) | lo;
-}
-
-struct UpdCell { int L, cell; float sa, sb, err; };
-
-// geometry of D1/Primitive.cu:278-307 for a pixel whose plane parameters Q are known
-__device__ __forceinline__ bool update_cell(const F3 &p, const float *__restrict__ Q, int N_prim, int M_prim, UpdCell &o) {
-    o.err = ((p.x * Q[0] + p.y * Q[1]) + p.z * Q[2]) - Q[3];
-    float a = (p.x * Q[8] + p.y * Q[9]) + p.z * Q[10];
-    float b = (p.x * Q[11] + p.y * Q[12]) + p.z * Q[13];
-    a = (float)((double)((a - Q[6]) * Q[4]) / 2.0);
-    b = (float)((double)((b - Q[7]) * Q[5]) / 2.0);
-    int ii = f2i_rd(a), jj = f2i_rd(b);
-    if (ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0) return false;
-    o.cell = ii * M_prim + jj; o.sa = a - (float)ii; o.sb = b - (float)jj;
-    return true;
-}
-
 // The per-pixel work is a chain of dependent gathers (label -> plane tables -> cell mask -> claim word -> stores).
 // A wavefront is 64 consecutive pixels of one image row and almost always sees ONE label: then the plane's table
 // entries and its 14 parameters are fetched once per wave through a wave-uniform address (scalar loads) instead of
@@ -215,6 +190,22 @@ extern "C" int rgbdslam_update_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_bl
     if (!pb) return RGBDSLAM_E_ARG;
     return launch_update(ctx, pb, nullptr, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, N_prim,
                          M_prim, n, m, plane_lo, plane_hi);
+}
+
+// second half of rgbdslam_update_tracked for callers whose claim pass rode on rgbdslam_model_merge_claim
+extern "C" int rgbdslam_update_apply_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, uint16_t **BumpTab, uint8_t **RGBTab,
+                                             uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp,
+                                             const float *VMap, const float *RGBD, const uint8_t *Mask, const uint8_t *Label,
+                                             int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi) {
+    if (!ctx || !pb || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !VMap || !RGBD || !Mask || !Label) return RGBDSLAM_E_ARG;
+    if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
+    if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
+    PoseV P;
+    for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
+    KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp,
+            VMap, RGBD, Mask, Label, P, pb, (const float *)nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int rgbdslam_update_from_history(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab,

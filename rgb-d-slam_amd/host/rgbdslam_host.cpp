@@ -370,7 +370,14 @@ void PredictedFrame::NormalSegmentFused(const rgbdslam_pose_block *pb, float *Eq
     check(rgbdslam_model_normal_segment(_ctx, pb, _NMap_dev.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans,
                                         0.1f, 0.9f, _n, _m), "model_normal_segment");
 }
-void PredictedFrame::MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame) {
+void PredictedFrame::MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame, const UpdateTables *claim) {
+    if (claim) {
+        check(rgbdslam_model_merge_claim(_ctx, pb, _RGB_alt.p, _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(),
+                                         _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p, _Label_dev, claim->Mask, claim->Param,
+                                         claim->Claim, claim->stamp, claim->N_prim, claim->M_prim, _n, _m, claim->plane_lo,
+                                         claim->plane_hi), "model_merge_claim");
+        return;
+    }
     check(rgbdslam_model_merge(_ctx, pb, _RGB_alt.p, _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(),
                                _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p, _n, _m), "model_merge");
 }
@@ -460,6 +467,19 @@ void Graph::Update(PredictedFrame *frame, float *pose) {
                           (uint64_t **)_ClaimTab.p, _stamp, frame->getVMap(), frame->getRGB(), frame->_Mask_dev,
                           frame->_Label_dev, pose, _SizeVBUFF[0], _SizeVBUFF[1], frame->_n, frame->_m, plane_lo, plane_hi),
           "Update_cu");                                                            // Graph.cpp:74
+}
+bool Graph::begin_update(UpdateTables *t) {
+    if (_nodes.size() == 0) return false;                                          // Graph.cpp:53-54
+    if (!_tables_built) build_tables();
+    _stamp++;
+    *t = UpdateTables{(uint16_t **)_BumpTab.p, (uint8_t **)_RGBTab.p, (uint8_t **)_MaskTab.p, (float **)_ParamTab.p,
+                      (uint64_t **)_ClaimTab.p, _stamp, _SizeVBUFF[0], _SizeVBUFF[1], plane_lo, plane_hi};
+    return true;
+}
+void Graph::ApplyTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t) {
+    check(rgbdslam_update_apply_tracked(_ctx, pb, t.Bump, t.RGB, t.Mask, t.Param, t.Claim, t.stamp, frame->getVMap(), frame->getRGB(),
+                                        frame->_Mask_dev, frame->_Label_dev, t.N_prim, t.M_prim, frame->_n, frame->_m, t.plane_lo,
+                                        t.plane_hi), "Update_cu (apply)");
 }
 void Graph::UpdateFromHistory(PredictedFrame *frame, const float *history_entry_dev) {
     if (_nodes.size() == 0) return;
@@ -897,10 +917,12 @@ int RG::StepAsync() {
     // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
     _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
     _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);       // Frame.cpp:242 + 395
-    _predicted_frame->MergeFused(_pb_dev, _frame);                                  // GP-demo.cpp:249
+    UpdateTables upd;
+    const bool claim_in_merge = !ov && _graph->begin_update(&upd);
+    _predicted_frame->MergeFused(_pb_dev, _frame, claim_in_merge ? &upd : nullptr);  // GP-demo.cpp:249 (+ claim pass of :260)
     if (ovl) _frame->release(main);                                                 // last reader of this frame's buffer set
     if (!ov) {
-        _graph->UpdateTracked(_predicted_frame, _pb_dev);                           // GP-demo.cpp:260
+        if (claim_in_merge) _graph->ApplyTracked(_predicted_frame, _pb_dev, upd);   // GP-demo.cpp:260
     } else {
         if (_graph->_nodes.size() != 0) {
             // Graph::Update on its own stream, posed by this frame's history entry (the pose block is rewritten

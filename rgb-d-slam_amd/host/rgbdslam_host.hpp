@@ -69,6 +69,13 @@ struct DevBuf {
 };
 
 // ---- D1/Frame.h:19-134 ------------------------------------------------------------------------
+// device pointer tables + stamp of one Graph::Update (Graph.cpp:56-70), handed to the fused merge+claim / apply pair
+struct UpdateTables {
+    uint16_t **Bump; uint8_t **RGB, **Mask; float **Param; uint64_t **Claim;
+    uint32_t stamp;
+    int N_prim, M_prim, plane_lo, plane_hi;
+};
+
 class InputFrame {
 public:
     InputFrame(rgbdslam_ctx *ctx, int n, int m);
@@ -143,7 +150,8 @@ public:
     void ReseedFused(const rgbdslam_pose_block *pb, int force, OffLineFrame *frame);       // Cpy + InitMask
     void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *reseed_from);   // Transform..ProjectLabel gather
     void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
-    void MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame);
+    // claim != null: the claim pass of the Graph::Update that follows rides on the merge launch
+    void MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame, const struct UpdateTables *claim = nullptr);
     float *getVMap() { return _VMap_dev.p; }
     float *getNMap() { return _NMap_dev.p; }
     float *getRGB() { return _RGB_dev.p; }
@@ -184,6 +192,10 @@ public:
     void Update(PredictedFrame *frame, float *pose);              // Graph.cpp:50-95
     void UpdateTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb);   // same, pose from the device block
     void UpdateFromHistory(PredictedFrame *frame, const float *history_entry_dev);   // same, pose from the frame's history entry
+    // split form: begin_update (tables + new stamp; false without planes), claim pass inside PredictedFrame::MergeFused,
+    // then ApplyTracked
+    bool begin_update(UpdateTables *t);
+    void ApplyTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t);
     void Clear();
     std::vector<Primitive *> _nodes;
     int _SizeVBUFF[2];
