@@ -244,6 +244,21 @@ void k_icp_iter(IcpIterArgs a) {
     long long ts0 = a.timing ? wall_clock64() : 0;
     if (a.timing && t == 0 && threadIdx.x == 0) a.timing[0] = ts0;
 
+    // Launches that follow a converged / failed iteration leave at once: the two flags are read through a uniform
+    // address before any LDS traffic or barrier (the host cannot know the iteration count, so it always enqueues
+    // max_iter + 2 launches per level; at [3,4,3] executed iterations two of the twelve are such no-ops).
+    if (a.state && !a.first_launch) {
+        const int cvg = a.state->cvg, fail = a.state->fail;
+        if (fail || (a.iter > 0 && cvg)) {
+            if (a.final_launch && t == 0 && threadIdx.x == 0) {
+                IcpState loc = *a.state;
+                IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
+                icp_end_step(&loc, e);
+            }
+            return;
+        }
+    }
+
     // First memory round trip: the state snapshot (last wave) and round 0's model pixels (all waves)
     // are requested together; nothing below waits on global memory until the gathers.
     if (wave == ICP_MAX_WAVES - 1) {
