@@ -155,6 +155,23 @@ def test_hip_path_reproduces_golden_fixture(pkg):
     rg.close()
 
 
+def test_hip_detection_reproduces_golden_fixture(pkg):
+    """HIP plane detection against the committed golden vectors (no oracle library involved)."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, want = np.load(os.path.join(here, "slam_96x128.npz")), np.load(os.path.join(here, "detect_96x128.npz"))
+    n, m = g["depth"].shape[1:]
+    rg = pkg.RG(n, m, g["calib"], N_prim=256, M_prim=256)
+    for f in range(3):
+        rg.load_frame(np.ascontiguousarray(g["depth"][f]), np.ascontiguousarray(g["bgr"][f]))
+        rg.step()
+    eq, ce = rg.detect_planes(300, 200)
+    same(eq, want["equations"], "equations")
+    same(ce, want["centers"], "centres")
+    same(rg.buffer("Label"), want["Label"], "Label")
+    rg.close()
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth, overlap):
     """run_device_sequence enqueues every frame without a host sync (pose history on the device);

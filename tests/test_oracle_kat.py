@@ -349,3 +349,76 @@ def test_oracle_reproduces_golden():
         else:
             assert np.array_equal(a, b), k
     assert list(g["status"]) == [2, 1, 1, 1, 1] and int(g["align_ok"][0]) == 1
+
+
+def test_oracle_reproduces_detection_golden(orc):
+    """oracle (plane detection) == tests/golden/detect_96x128.npz, recomputed from the slam fixture's inputs."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_detect", os.path.join(here, "make_golden_detect.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = np.load(os.path.join(here, "detect_96x128.npz"))
+    got = mod.run_oracle(orc, np.load(os.path.join(here, "slam_96x128.npz")))
+    assert set(got) == set(want.files)
+    for k in want.files:
+        assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), k
+    assert want["equations"].shape == (3, 10)
+
+
+# ---- plane detection (SURVEY 8f N1): closed-form answers ---------------------------------------------
+def test_detect_canny_step_and_flat(orc):
+    img = np.full((20, 30), 40, np.uint8)
+    assert not orc.canny(img).any()                                  # no gradient, no edge
+    img[:, 15:] = 200                                                # |dx| = 4 * 160 = 640 > 120 on columns 14 and 15
+    e = orc.canny(img)
+    cols = np.nonzero(e.any(axis=0))[0]
+    # equal magnitudes on both sides of the step: "m > left && m >= right" keeps exactly the left one
+    assert list(cols) == [14] and (e[:, 14] == 255).all()
+    weak = np.full((20, 30), 40, np.uint8)
+    weak[:, 15:] = 50                                                # |dx| = 40: above low (30), below high (120), no strong seed
+    assert not orc.canny(weak).any()
+    same = orc.canny(img, 30.0, 120.0)
+    assert np.array_equal(same, e)                                   # RG.cpp passes (120, 30): OpenCV swaps them
+
+
+def test_detect_blobs_and_erode(orc):
+    b = np.zeros((6, 8), np.uint8)
+    b[0, 0:3] = 1; b[1, 2] = 1                                       # blob A: 4 pixels, first pixel index 0
+    b[3:5, 5:7] = 1                                                  # blob B: 4 pixels, first pixel (3,5) = 29
+    b[5, 7] = 1                                                      # touches B only diagonally: its own blob (4-connectivity)
+    blob, sizes = orc.find_blobs(b)
+    assert sizes[0, 0] == 4 and sizes[3, 5] == 4 and sizes[5, 7] == 1 and sizes.sum() == 9
+    assert (blob[b > 0] >= 0).all() and (blob[b == 0] == -1).all()
+    assert blob[1, 2] == 0 and blob[4, 6] == 29 and blob[5, 7] == 47
+    full = np.full((7, 7), 255, np.uint8)
+    assert (orc.erode_ellipse5(full) == 255).all()                   # pixels outside the image do not constrain
+    full[0, 0] = 0
+    er = orc.erode_ellipse5(full)
+    assert er[0, 0] == 0 and er[0, 2] == 0 and er[2, 0] == 0 and er[1, 2] == 0 and er[1, 1] == 0
+    assert er[2, 1] == 255 and er[2, 2] == 255 and er[0, 3] == 255   # rows +-2 of the ellipse hold the centre column only
+
+
+def test_detect_plane_fit_closed_form(orc):
+    """A fronto-parallel wall at z = -2 (camera looks down -z), unit normals (0,0,1), identity pose: the median fit
+    must return exactly n = (0,0,1), d = -2, the basis the reference's rule picks, and the mean point."""
+    n, m = 40, 50
+    v = np.zeros((n, m, 3), np.float32)
+    v[..., 0] = np.linspace(-1, 1, m, dtype=np.float32)[None, :]
+    v[..., 1] = np.linspace(-0.8, 0.8, n, dtype=np.float32)[:, None]
+    v[..., 2] = -2.0
+    nm = np.zeros((n, m, 3), np.float32)
+    nm[..., 2] = 1.0
+    nm[0, :] = 0.0                                                   # a row without normals: its zeros stay in the median lists
+    blob = np.zeros((n, m), np.int32)
+    sizes = np.zeros((n, m), np.int32)
+    sizes[0, 0] = n * m
+    I16 = np.eye(4, dtype=np.float32).reshape(-1)
+    nb, eq, ce, lab = orc.fit_planes(blob, sizes, v, nm, I16, np.zeros((n, m), np.uint8), min_size=100, min_normals=100)
+    assert nb == 1 and (lab == 1).all()
+    assert np.array_equal(eq[0], np.float32([0, 0, 1, 1, 0, 0, 0, 1, 0, -2]))   # e1 = (n2, 0, -n0), e2 = n x e1
+    assert np.allclose(ce[0], v.reshape(-1, 3).mean(0), atol=1e-4)
+    # too small / too few normals: no plane
+    assert orc.fit_planes(blob, sizes, v, nm, I16, np.zeros((n, m), np.uint8), min_size=n * m, min_normals=100)[0] == 0
+    assert orc.fit_planes(blob, sizes, v, nm, I16, np.zeros((n, m), np.uint8), min_size=100, min_normals=n * m)[0] == 0
