@@ -205,7 +205,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # frame 0 seeds the model; planes are injected once (plane detection is SURVEY 8f "next")
+    # frame 0 seeds the model; the three planes are injected analytically (BASELINE configs[1]: "equations supplied");
+    # RG.detect_planes() is the detection path (tests/test_gpu_slam_loop.py::test_loop_with_detected_planes)
     run(order[:1])
     rg.set_planes(eq, centers)
     pos = 1
