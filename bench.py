@@ -37,7 +37,7 @@ POOL_FRAMES = 60           # distinct synthetic frames, visited ping-pong so ste
 # Algorithmic bytes per unit (SURVEY.md 8d / DESIGN.md "kernels"), per launch of each kernel.
 def algo_bytes(kernel, n, m, level_iters):
     P = n * m
-    if kernel == "k_icp_iter":
+    if kernel in ("k_icp_iter", "k_icp_loop"):
         # 80 B per sampled model pixel per executed iteration, all three levels summed
         return sum(80 * (n // f) * (m // f) * it for f, it in zip((1, 2, 4), level_iters))
     return PER_PX[kernel] * P
@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--kernel", default="k_icp_iter", help="kernel whose roofline is reported")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--icp-loop", type=int, default=0, help="1: persistent-loop ICP (rgbdslam_set_icp_loop)")
     ap.add_argument("--no-large-kernels", action="store_true", help="skip the config-3/config-4-size kernel rooflines")
     ap.add_argument("--profile-in-timed-region", action="store_true",
                     help="record the roofline events inside the timed region instead of in a second pass")
@@ -195,6 +196,10 @@ def main():
     host.slamhost_rg_ctx.restype = C.c_void_p
     ctx = C.c_void_p(host.slamhost_rg_ctx(rg._h))
     eq, centers = synth.plane_equations()
+    if args.icp_loop:
+        rg.set_icp_loop(True)
+        if args.kernel == "k_icp_iter":
+            args.kernel = "k_icp_loop"
 
     def run(frames):
         return rg.run_device_sequence([depth_dev[i] for i in frames], [bgr_dev[i] for i in frames])

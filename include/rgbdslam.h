@@ -119,6 +119,17 @@ int rgbdslam_align_gauss_newton(rgbdslam_ctx *ctx, const rgbdslam_icp_params *pr
                                 const float *RGB_prev, int n_row, int m_col,
                                 float *pose_state_dev, int32_t *status_dev, float *trace_dev);
 
+/* Persistent-loop mode of rgbdslam_track_frame: all Gauss-Newton iterations of a frame (the loop of
+ * D1/RG.cpp:838-903) run inside ONE kernel launch, the iterations separated by a device-wide epoch word
+ * instead of kernel boundaries.  Same arithmetic, same results.  The kernel needs all of its 512
+ * workgroups on the device at once, i.e. this process has the GPU to itself and the frame loop uses one
+ * stream; the mode is therefore off unless the caller opts in (or RGBDSLAM_ICP_LOOP=1 is set when the
+ * buffers are allocated).  Returns RGBDSLAM_E_STATE when the device cannot hold the grid.  A launch
+ * whose workgroups give up waiting (50 ms) marks the frame as lost and raises the fault count. */
+int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on);
+/* faults[0] = launches that gave up since the last call; synchronises the stream.  A fault switches the mode off. */
+int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults);
+
 /* Row-sharded form of the same loop (no reference counterpart: the reference is single-GPU;
  * SURVEY.md 8e / BASELINE.json configs[3]).  Each rank owns the 8x8-block rows
  * [block_row_lo, block_row_hi) of the level's block grid (divUp(n/2^lvl, 8) rows) and produces its

@@ -299,6 +299,17 @@ class RG:
         _hchk(self.lib.slamhost_rg_history(self._h, int(first), int(count), C.c_void_p(out.ctypes.data)), "history")
         return out
 
+    def set_icp_loop(self, on):
+        """True: all Gauss-Newton iterations of a frame run in ONE persistent kernel (needs the GPU to itself and a single
+        stream; same results).  Raises when the device cannot hold the kernel's 512 workgroups at once."""
+        _hchk(self.lib.slamhost_rg_set_icp_loop(self._h, int(on)), "set_icp_loop")
+
+    def icp_loop_faults(self):
+        """Persistent-loop launches that gave up waiting since the last call (synchronises); a fault switches the mode off."""
+        f = C.c_int(0)
+        _hchk(self.lib.slamhost_rg_icp_loop_faults(self._h, C.byref(f)), "icp_loop_faults")
+        return f.value
+
     def set_device_loop(self, on):
         _hchk(self.lib.slamhost_rg_set_device_loop(self._h, int(on)), "set_device_loop")
 

@@ -40,6 +40,10 @@ struct rgbdslam_ctx {
     float *outbuf_dev;   // f32[27]
     float *out_host;     // pinned f32[27]
     IcpState *icp_state; // device
+    char *icp_block;               // the one allocation behind buf_dev / ticket_dev / outbuf_dev / icp_state / icp_epoch_dev
+    unsigned int *icp_epoch_dev;   // k_icp_loop: [0] epoch word, [32] fault flag
+    unsigned int icp_epoch_base;   // host-side monotonic base of the epoch word
+    int icp_loop;                  // rgbdslam_set_icp_loop
     // instrumentation (rgbdslam_profile_*): HIP-event pairs around every launch of one named kernel
     const char *prof_name;
     hipEvent_t *prof_ev;   // 2 * prof_cap events

@@ -220,37 +220,64 @@ struct IcpIterArgs {
 // determinant test, thread 0 the Cholesky solve and the pose update.  st = working copy of the state
 // (LDS), out = device-resident state it is committed to, sh = 2 floats of LDS.
 struct IcpEndArgs { float *pose_state; int32_t *status; rgbdslam_pose_block *pb; float *history; int frame_index; };
+// persistent loop: epoch word = base + index of the next step that executes (>= nsteps: finished)
+struct IcpLoopCtl { unsigned int *epoch; unsigned int base; int step, next_level, nsteps; };
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
-                                               bool with_end, IcpEndArgs end);
+                                               bool with_end, IcpEndArgs end, IcpLoopCtl lc);
 __device__ __forceinline__ void icp_begin_step(IcpState *st, const float *pose_state, const float *intr4);
 __device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArgs &e);
 
-// 6 waves per SIMD (<= 80 VGPRs): two 10-wave workgroups per CU, so all 512 chains are resident at once
-__global__ __launch_bounds__(64 * ICP_MAX_WAVES)
-void k_icp_iter(IcpIterArgs a) {
-    __shared__ float part[ICP_MAX_WAVES][27];
-    __shared__ __attribute__((aligned(16))) float tr[ICP_MAX_WAVES][27 * 8];
-    __shared__ float fin[27];
-    __shared__ float solve_sh[2];
-    __shared__ IcpState sst;          // snapshot of the loop state (or of the caller's R, t, intr)
-    __shared__ float spose[24];       // pose_state snapshot for the solve
-    __shared__ int last_flag;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x;
+// LDS of one workgroup of the iteration kernels
+struct IcpShared {
+    float (&part)[ICP_MAX_WAVES][27];
+    float (&tr)[ICP_MAX_WAVES][27 * 8];
+    float (&fin)[27];
+    float (&solve_sh)[2];
+    IcpState &sst;         // snapshot of the loop state (or of the caller's R, t, intr)
+    float (&spose)[24];    // pose_state snapshot for the solve
+    int &last_flag;
+};
+#define ICP_SHARED_DECL(S)                                                       \
+    __shared__ float part_[ICP_MAX_WAVES][27];                                   \
+    __shared__ __attribute__((aligned(16))) float tr_[ICP_MAX_WAVES][27 * 8];    \
+    __shared__ float fin_[27];                                                   \
+    __shared__ float solve_sh_[2];                                               \
+    __shared__ IcpState sst_;                                                    \
+    __shared__ float spose_[24];                                                 \
+    __shared__ int last_flag_;                                                   \
+    IcpShared S = {part_, tr_, fin_, solve_sh_, sst_, spose_, last_flag_}
+
+// One iteration as seen by workgroup blockIdx.x.  LOOP = called from the persistent k_icp_loop: the
+// state changes while the kernel runs, so it is read and written with agent-scope atomics (plain
+// loads could be served from a stale scalar or vector L1 line), and the tail publishes the next step.
+// persistent loop: the model pixels a wave samples in its first two rounds are the same for every iteration of a
+// level (only the pose changes), so they stay in registers from one step to the next
+struct IcpModelCache { IcpModelPx r0, r1; int lvl; };
+template <bool LOOP>
+__device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpShared &S, IcpLoopCtl lc, const int tid, const int t,
+                                              IcpModelCache &mc) {
+    float (&part)[ICP_MAX_WAVES][27] = S.part;
+    float (&tr)[ICP_MAX_WAVES][27 * 8] = S.tr;
+    float (&fin)[27] = S.fin;
+    float (&solve_sh)[2] = S.solve_sh;
+    IcpState &sst = S.sst;
+    float (&spose)[24] = S.spose;
+    int &last_flag = S.last_flag;
+    const int wave = tid >> 6, lane = tid & 63;
     const int nblk = a.rows_local * a.grid_cols;
     const int chain_len = (nblk - t + ICP_CHAINS - 1) / ICP_CHAINS;
     const int rounds = (chain_len + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES;
     long long ts0 = a.timing ? wall_clock64() : 0;
-    if (a.timing && t == 0 && threadIdx.x == 0) a.timing[0] = ts0;
+    if (a.timing && t == 0 && tid == 0) a.timing[0] = ts0;
 
     // Launches that follow a converged / failed iteration leave at once: the two flags are read through a uniform
     // address before any LDS traffic or barrier (the host cannot know the iteration count, so it always enqueues
     // max_iter + 2 launches per level; at [3,4,3] executed iterations two of the twelve are such no-ops).
-    if (a.state && !a.first_launch) {
+    if (!LOOP && a.state && !a.first_launch) {
         const int cvg = a.state->cvg, fail = a.state->fail;
         if (fail || (a.iter > 0 && cvg)) {
-            if (a.final_launch && t == 0 && threadIdx.x == 0) {
+            if (a.final_launch && t == 0 && tid == 0) {
                 IcpState loc = *a.state;
                 IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
                 icp_end_step(&loc, e);
@@ -267,7 +294,10 @@ void k_icp_iter(IcpIterArgs a) {
             const float *src = (const float *)a.state;
             if (a.pose_state && lane < 24) spose[lane] = a.pose_state[lane];
             if (!a.first_launch) {
-                if (lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
+                if (LOOP) {
+                    if (lane < (int)(sizeof(IcpState) / 4))
+                        dst[lane] = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -292,10 +322,17 @@ void k_icp_iter(IcpIterArgs a) {
         inside = (i * a.fact < a.n && j * a.fact < a.m);
         idx = inside ? (size_t)(i * a.fact) * a.m + (size_t)(j * a.fact) : 0;
     };
-    if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+    if (LOOP) {
+        if (mc.lvl != a.lvl) {                        // first step of a level: both rounds' pixels are requested at once
+            if (wave + ICP_MAX_WAVES < chain_len) { locate(wave + ICP_MAX_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+            if (active) { locate(k); mc.r0 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+            mc.lvl = a.lvl;
+        } else if (active) locate(k);
+        mp = mc.r0;
+    } else if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
     __syncthreads();
-    if (sst.fail || (a.iter > 0 && sst.cvg)) {        // converged / failed earlier: the whole grid leaves
-        if (a.final_launch && t == 0 && threadIdx.x == 0) {
+    if (!LOOP && (sst.fail || (a.iter > 0 && sst.cvg))) {   // converged / failed earlier: the whole grid leaves
+        if (a.final_launch && t == 0 && tid == 0) {
             IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
             icp_end_step(&sst, e);
         }
@@ -307,7 +344,11 @@ void k_icp_iter(IcpIterArgs a) {
         if (r > 0) {
             k = r * ICP_MAX_WAVES + wave;
             active = k < chain_len;
-            if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+            if (active) {
+                locate(k);
+                if (LOOP && r == 1) mp = mc.r1;
+                else mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev);
+            }
         }
         if (active) {
             IcpRow q;
@@ -351,7 +392,7 @@ void k_icp_iter(IcpIterArgs a) {
     // Two-level arrival counter (same-address device-scope atomics serialise at the memory side):
     // 16 workgroups share a group counter on its own 128-byte line, the last arrival of a group
     // bumps the top counter, the last arrival there owns the tail.
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         int g = t / ICP_TICKET_GROUP, ngroups = (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP;
         unsigned int expect = (unsigned int)min(ICP_TICKET_GROUP, a.nchain - g * ICP_TICKET_GROUP);
         unsigned int old = __hip_atomic_fetch_add(a.ticket + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -402,15 +443,135 @@ void k_icp_iter(IcpIterArgs a) {
         if (lane == 0 && term < 27) { fin[term] = s; a.sums[term] = s; }
     }
     long long ts4 = a.timing ? wall_clock64() : 0;
-    if (threadIdx.x <= (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) a.ticket[32 * threadIdx.x] = 0u;   // ready for the next launch
+    if (tid <= (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) {   // ready for the next launch / step
+        if (LOOP) __hip_atomic_store(a.ticket + 32 * tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.ticket[32 * tid] = 0u;
+    }
+    if (LOOP) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the resets have landed before the epoch moves
     __syncthreads();
     if (a.do_solve) {
         IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
         icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh,
-                       a.final_launch != 0, e);        // by value: a pointer to the local would put it in scratch memory
+                       a.final_launch != 0, e, lc);    // by value: a pointer to the local would put it in scratch memory
     }
-    if (a.timing && threadIdx.x == 0) {
+    if (a.timing && tid == 0) {
         a.timing[1] = ts0; a.timing[2] = ts1; a.timing[3] = ts2; a.timing[4] = ts3; a.timing[5] = ts4; a.timing[6] = wall_clock64();
+    }
+}
+
+// 5 waves per SIMD (<= 96 VGPRs): two 5-wave workgroups per CU, so all 512 chains are resident at once
+__global__ __launch_bounds__(64 * ICP_MAX_WAVES)
+void k_icp_iter(IcpIterArgs a) {
+    ICP_SHARED_DECL(S);
+    IcpModelCache mc;
+    icp_iter_body<false>(a, S, IcpLoopCtl{nullptr, 0u, 0, 0, 0}, (int)threadIdx.x, (int)blockIdx.x, mc);
+}
+
+// ---- persistent coarse-to-fine loop: ALL iterations of a frame in one launch -----------------------
+// Workgroup t keeps chain t for every step.  Between two Gauss-Newton iterations the grid meets at an
+// epoch word: the tail workgroup of step s (the last one through the ticket counter) solves, commits
+// the state and stores base + (next step that executes) -- the steps the multi-launch loop would have
+// started as no-ops (after convergence) are jumped over; >= nsteps ends the kernel.  The host only
+// launches this kernel when every workgroup fits on the device at once (rgbdslam_set_icp_loop), and a
+// waiting workgroup gives up after timeout_ticks so that every wave reaches an exit even if that
+// assumption is broken by another process sharing the device.
+// steps are numbered through the levels, coarse to fine; level k owns [start, start + max_iter + 2)
+struct IcpLoopLevel { int start, grid_rows, grid_cols, lvl, max_iter; };
+// The argument block is kept small on purpose: every field stays in a scalar register for the whole
+// loop, and what does not fit is spilled into vector registers and scratch memory.  The five ICP work
+// buffers are therefore one allocation with fixed offsets, and pose_state / status come from pb.
+#define ICP_OFF_CHAINS 0
+#define ICP_OFF_TICKET (27 * ICP_CHAINS * 4)
+#define ICP_OFF_OUT (ICP_OFF_TICKET + ICP_TICKET_WORDS * 4)
+#define ICP_OFF_STATE (ICP_OFF_OUT + 128)
+#define ICP_OFF_EPOCH (ICP_OFF_STATE + 128)      // epoch word; fault flag 128 bytes further
+#define ICP_BLOCK_BYTES (ICP_OFF_EPOCH + 256)
+static_assert(sizeof(IcpState) <= 128, "state slot");
+struct IcpLoopArgs {
+    const float *VMap, *NMap, *RGB, *Gx, *Gy, *VMap_prev, *NMap_prev, *RGBD_prev;
+    unsigned int gxp, gyp;
+    char *block;                                     // the ICP work block (offsets above)
+    rgbdslam_pose_block *pb;
+    float *history;
+    int frame_index;
+    float distThres, angleThres, thr_alpha, thr_tr;
+    int n, m;
+    float intr4[4];
+    IcpLoopLevel lv[3];                              // unused entries: start = INT_MAX
+    int nsteps;
+    unsigned int epoch_base;
+    int timeout_ticks;
+};
+
+__global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(4)))
+void k_icp_loop(IcpLoopArgs L) {
+    ICP_SHARED_DECL(S);
+    __shared__ int next_step;
+    const int t = blockIdx.x;
+    unsigned int *const epoch = (unsigned int *)(L.block + ICP_OFF_EPOCH);
+    int s = 0;
+    IcpModelCache mc;
+    mc.lvl = -1;
+    for (;;) {
+        // the level's constants are picked with uniform selects (a dynamically indexed kernarg array would be
+        // copied to scratch memory and turn every one of them into a vector register)
+        // fresh (opaque) thread and workgroup ids every step: otherwise the compiler hoists every address it can
+        // form from them out of the loop and then spills those registers to scratch memory
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const bool in2 = s >= L.lv[2].start, in1 = s >= L.lv[1].start;
+#define ICP_LV(f) (in2 ? L.lv[2].f : (in1 ? L.lv[1].f : L.lv[0].f))
+        const int grid_rows = ICP_LV(grid_rows), grid_cols = ICP_LV(grid_cols);
+        const int nchain = min(grid_rows * grid_cols, ICP_CHAINS);
+        if (t < nchain) {
+            IcpIterArgs a;
+            a.intr = nullptr; a.R = nullptr; a.t = nullptr;
+            a.VMap = L.VMap; a.NMap = L.NMap; a.RGB = L.RGB; a.Gx = L.Gx; a.Gy = L.Gy; a.gxp = L.gxp; a.gyp = L.gyp;
+            a.VMap_prev = L.VMap_prev; a.NMap_prev = L.NMap_prev; a.RGBD_prev = L.RGBD_prev;
+            a.distThres = L.distThres; a.angleThres = L.angleThres;
+            a.n = L.n; a.m = L.m;
+            a.lvl = ICP_LV(lvl); a.max_iter = ICP_LV(max_iter);
+            a.fact = 1 << a.lvl; a.grid_rows = grid_rows; a.grid_cols = grid_cols;
+            a.br_lo = 0; a.rows_local = grid_rows; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
+            a.chains = (float *)(L.block + ICP_OFF_CHAINS); a.ticket = (unsigned int *)(L.block + ICP_OFF_TICKET);
+            a.sums = (float *)(L.block + ICP_OFF_OUT); a.corr = nullptr;
+            a.state = (IcpState *)(L.block + ICP_OFF_STATE); a.pose_state = L.pb->pose_state;
+            a.do_solve = 1;
+            const int start = ICP_LV(start);
+            a.iter = s - start;
+            a.thr_alpha = L.thr_alpha; a.thr_tr = L.thr_tr; a.trace = nullptr; a.timing = nullptr;
+            a.first_launch = (s == 0); a.final_launch = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) a.intr4[k] = L.intr4[k];
+            a.pose_state_rw = L.pb->pose_state; a.status = L.pb->status; a.pb = L.pb; a.history = L.history;
+            a.frame_index = L.frame_index;
+            icp_iter_body<true>(a, S, IcpLoopCtl{epoch, L.epoch_base, s, start + a.max_iter + 2, L.nsteps}, tid, t, mc);
+        }
+#undef ICP_LV
+        __syncthreads();                               // every thread is done with S
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            int nxt;
+            for (;;) {
+                const unsigned int e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int d = (int)(e - L.epoch_base);
+                if (d > s) { nxt = d; break; }
+                if (wall_clock64() - t0 > (long long)L.timeout_ticks) { nxt = -1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            next_step = nxt;
+        }
+        __syncthreads();
+        const int nxt = next_step;
+        if (nxt < 0) {                                 // broken residency assumption: report and leave
+            if (threadIdx.x == 0) {
+                __hip_atomic_store((int *)(L.block + ICP_OFF_EPOCH + 128), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == 0) L.pb->status[0] = 0;
+            }
+            return;
+        }
+        if (nxt >= L.nsteps) return;
+        s = nxt;
     }
 }
 
@@ -607,7 +768,7 @@ __device__ __forceinline__ void icp_pose_update(IcpState *st, const float *x, co
 
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
-                                               bool with_end, IcpEndArgs end) {
+                                               bool with_end, IcpEndArgs end, IcpLoopCtl lc) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float x[6];
     int llt_fail = 0;
@@ -631,6 +792,24 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         }
         icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
     }
+    if (lc.epoch) {
+        // persistent loop: the state is committed with write-through stores, then the epoch names the next
+        // step that executes (a failed solve ends the loop, a converged level continues at the next level)
+        const int nxt = loc.fail ? lc.nsteps : (loc.cvg ? lc.next_level : lc.step + 1);
+#define ICP_PUB(dst, v) __hip_atomic_store(&(dst), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#pragma unroll
+        for (int k = 0; k < 9; k++) { ICP_PUB(out->Rinv[k], loc.Rinv[k]); ICP_PUB(out->Rcurr[k], loc.Rcurr[k]); }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ICP_PUB(out->tinv[k], loc.tinv[k]); ICP_PUB(out->tcurr[k], loc.tcurr[k]); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) ICP_PUB(out->intr[k], loc.intr[k]);
+        ICP_PUB(out->cvg, loc.cvg); ICP_PUB(out->fail, loc.fail); ICP_PUB(out->iters, loc.iters); ICP_PUB(out->lvl_iters, loc.lvl_iters);
+#undef ICP_PUB
+        if (nxt >= lc.nsteps) icp_end_step(&loc, end);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(lc.epoch, lc.base + (unsigned int)nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     *out = loc;
     if (with_end) icp_end_step(&loc, end);
 }
@@ -653,7 +832,8 @@ void k_icp_solve(IcpState *st, const float *__restrict__ gathered, int parts, co
     }
     __syncthreads();
     if (sst.fail || (iter > 0 && sst.cvg)) return;
-    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh, false, IcpEndArgs{nullptr, nullptr, nullptr, nullptr, 0});
+    icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh, false, IcpEndArgs{nullptr, nullptr, nullptr, nullptr, 0},
+                   IcpLoopCtl{nullptr, 0u, 0, 0, 0});
 }
 
 __device__ __forceinline__ void d_pack_pose(const float *R, const float *t, float *P) {   // GP-demo.cpp:206-211
@@ -732,24 +912,71 @@ extern "C" int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid
     // reduction stage never leaves the chip, so the scratch is 27 x 512 chain sums whatever the image size.
     if (!ctx || grid_rows <= 0 || grid_cols <= 0) return RGBDSLAM_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!ctx->buf_dev) HIP_TRY(hipMalloc((void **)&ctx->buf_dev, 27 * ICP_CHAINS * sizeof(float)));
-    if (!ctx->ticket_dev) {
-        HIP_TRY(hipMalloc((void **)&ctx->ticket_dev, ICP_TICKET_WORDS * sizeof(unsigned int)));
-        HIP_TRY(hipMemset(ctx->ticket_dev, 0, ICP_TICKET_WORDS * sizeof(unsigned int)));
+    if (!ctx->icp_block) {                                     // one allocation: k_icp_loop addresses it by offset
+        HIP_TRY(hipMalloc((void **)&ctx->icp_block, ICP_BLOCK_BYTES));
+        HIP_TRY(hipMemset(ctx->icp_block, 0, ICP_BLOCK_BYTES));
+        ctx->buf_dev = (float *)(ctx->icp_block + ICP_OFF_CHAINS);
+        ctx->ticket_dev = (unsigned int *)(ctx->icp_block + ICP_OFF_TICKET);
+        ctx->outbuf_dev = (float *)(ctx->icp_block + ICP_OFF_OUT);
+        ctx->icp_state = (IcpState *)(ctx->icp_block + ICP_OFF_STATE);
+        ctx->icp_epoch_dev = (unsigned int *)(ctx->icp_block + ICP_OFF_EPOCH);
+        ctx->icp_epoch_base = 0;
     }
-    if (!ctx->outbuf_dev) HIP_TRY(hipMalloc((void **)&ctx->outbuf_dev, 27 * sizeof(float)));
     if (!ctx->out_host) HIP_TRY(hipHostMalloc((void **)&ctx->out_host, 27 * sizeof(float), hipHostMallocDefault));
-    if (!ctx->icp_state) HIP_TRY(hipMalloc((void **)&ctx->icp_state, sizeof(IcpState)));
+    const char *env = getenv("RGBDSLAM_ICP_LOOP");            // opt-in without touching the caller's code
+    if (env && atoi(env) > 0) (void)rgbdslam_set_icp_loop(ctx, 1);
     return 0;
 }
 
 extern "C" int rgbdslam_free_buffers(rgbdslam_ctx *ctx) {
     if (!ctx) return RGBDSLAM_E_ARG;
-    if (ctx->buf_dev) { (void)hipFree(ctx->buf_dev); ctx->buf_dev = nullptr; }
-    if (ctx->ticket_dev) { (void)hipFree(ctx->ticket_dev); ctx->ticket_dev = nullptr; }
-    if (ctx->outbuf_dev) { (void)hipFree(ctx->outbuf_dev); ctx->outbuf_dev = nullptr; }
+    if (ctx->icp_block) { (void)hipFree(ctx->icp_block); ctx->icp_block = nullptr; }
+    ctx->buf_dev = nullptr; ctx->ticket_dev = nullptr; ctx->outbuf_dev = nullptr; ctx->icp_state = nullptr; ctx->icp_epoch_dev = nullptr;
     if (ctx->out_host) { (void)hipHostFree(ctx->out_host); ctx->out_host = nullptr; }
-    if (ctx->icp_state) { (void)hipFree(ctx->icp_state); ctx->icp_state = nullptr; }
+    return 0;
+}
+
+// Persistent-loop mode of rgbdslam_track_frame (k_icp_loop).  It needs every one of its 512 workgroups on
+// the device at the same time, which holds when this process has the GPU to itself and the frame loop
+// runs on one stream (the one-process-per-GPU deployment): off by default, the caller opts in.
+extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    if (!on) { ctx->icp_loop = 0; return 0; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_loop, 64 * ICP_MAX_WAVES, 0));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    if (cus <= 0 || (long)per_cu * cus < ICP_CHAINS) return RGBDSLAM_E_STATE;
+    // The occupancy query packs waves freely over the four SIMDs of a CU; the dispatcher deals a workgroup's waves
+    // to the SIMDs starting from the first one (measured: at 144 registers = 3 waves per SIMD only ONE 5-wave
+    // workgroup was resident per CU and the loop starved), so SIMD 0 must have room for every workgroup's share.
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_icp_loop));
+    const int regs = ((fa.numRegs > 0 ? fa.numRegs : 512) + 7) & ~7;
+    const int waves_per_simd = 512 / regs < 8 ? 512 / regs : 8;
+    const int wgs_per_cu = (ICP_CHAINS + cus - 1) / cus;
+    if (wgs_per_cu * ((ICP_MAX_WAVES + 3) / 4) > waves_per_simd) return RGBDSLAM_E_STATE;
+    ctx->icp_loop = 1;
+    return 0;
+}
+
+// faults[0] = number of k_icp_loop launches that gave up waiting since the last call (synchronises the
+// stream).  After a fault the arrival counters are reset and the mode is switched off.
+extern "C" int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults) {
+    if (!ctx || !faults) return RGBDSLAM_E_ARG;
+    *faults = 0;
+    if (!ctx->icp_epoch_dev) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int f = 0;
+    HIP_TRY(hipMemcpyAsync(&f, ctx->icp_epoch_dev + 32, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (f) {
+        HIP_TRY(hipMemsetAsync(ctx->icp_epoch_dev + 32, 0, sizeof(int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->ticket_dev, 0, ICP_TICKET_WORDS * sizeof(unsigned int), ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->icp_loop = 0;
+    }
+    *faults = f;
     return 0;
 }
 
@@ -845,6 +1072,35 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
     IcpEndArgs end = {pose_state_dev, status_dev, pose_block, history, frame_index};
     if (!ride) KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
     int fact = 1 << (prm->lvl - 1);                            // RG.cpp:832
+    if (ride && ctx->icp_loop && ctx->icp_block && !trace_dev && pose_state_dev == pose_block->pose_state &&
+        status_dev == pose_block->status) {
+        IcpLoopArgs L;
+        int ns = 0, nl = 0;
+        for (int lvl = prm->lvl - 1, f = fact; lvl > -1; lvl--, f /= 2, nl++) {
+            if (prm->max_iter[lvl] < 0 || prm->max_iter[lvl] > 1000) return RGBDSLAM_E_ARG;
+            const int gr = div_up(n / f, 8), gc = div_up(m / f, 8);   // D1/ICP.cu:260-261
+            if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
+            IcpLoopLevel &lv = L.lv[nl];
+            lv.start = ns; lv.grid_rows = gr; lv.grid_cols = gc; lv.lvl = lvl; lv.max_iter = prm->max_iter[lvl];
+            ns += prm->max_iter[lvl] + 2;                      // iter = 0 .. max_iter+1 (RG.cpp:889)
+        }
+        for (int k = nl; k < 3; k++) { L.lv[k] = L.lv[0]; L.lv[k].start = 0x7fffffff; }
+        if (gxp > 0xffffffffu || gyp > 0xffffffffu) return RGBDSLAM_E_ARG;
+        L.VMap = VMap; L.NMap = NMap; L.RGB = RGB; L.Gx = Gx; L.Gy = Gy; L.gxp = (unsigned int)gxp; L.gyp = (unsigned int)gyp;
+        L.VMap_prev = VMap_prev; L.NMap_prev = NMap_prev; L.RGBD_prev = RGB_prev;
+        L.block = ctx->icp_block; L.pb = pose_block; L.history = history; L.frame_index = frame_index;
+        L.distThres = prm->distThres; L.angleThres = prm->angleThres;
+        L.thr_alpha = prm->thres_cvg_alpha; L.thr_tr = prm->thres_cvg_tr;
+        L.n = n; L.m = m;
+        for (int k = 0; k < 4; k++) L.intr4[k] = ctx->calib.v[k];
+        L.nsteps = ns;
+        ctx->icp_epoch_base += 4096u;                          // > any step index: a stale word never releases a waiter
+        L.epoch_base = ctx->icp_epoch_base;
+        L.timeout_ticks = 5000000;                             // 50 ms of the 100 MHz wall clock
+        KLAUNCH(ctx, k_icp_loop, dim3(ICP_CHAINS), dim3(64 * ICP_MAX_WAVES), L);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // instrumentation: the loop's launches are back to back, so one event pair brackets all of them
     const bool prof_group = prof_group_begin(ctx, "k_icp_iter");
     for (int lvl = prm->lvl - 1; lvl > -1; lvl--) {

@@ -1067,6 +1067,15 @@ int slamhost_rg_history(void *rg, int first, int count, float *out) {
     for (int k = 0; k < count; k++) memcpy(out + 16 * (size_t)k, r->history_host(first + k), 64);
     return 0;
 }
+// persistent-loop ICP (rgbdslam_set_icp_loop): one launch per frame for the whole coarse-to-fine loop
+int slamhost_rg_set_icp_loop(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    return rgbdslam_set_icp_loop(((RG *)rg)->ctx(), on);
+}
+int slamhost_rg_icp_loop_faults(void *rg, int *faults) {
+    if (!rg || !faults) return RGBDSLAM_E_ARG;
+    return rgbdslam_icp_loop_faults(((RG *)rg)->ctx(), faults);
+}
 int slamhost_rg_set_index_buffer(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     ((RG *)rg)->_predicted_frame->use_index_buffer = on != 0;

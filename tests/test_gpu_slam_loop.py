@@ -21,7 +21,8 @@ def same(a, b, what):
     assert ok.all(), "%s: mismatch at %d of %d elements" % (what, (~ok).sum(), ok.size)
 
 
-def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True, index_buffer=False, noise=0.0, fused=True, overlap=False):
+def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True, index_buffer=False, noise=0.0, fused=True, overlap=False,
+             icp_loop=False):
     calib = synth.calib_for(n, m)
     seq = synth.sequence(frames, n, m, calib, noise_sigma=noise)
     eq, centers = synth.plane_equations()
@@ -31,6 +32,8 @@ def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True,
     rg.set_overlap(overlap)
     rg.set_device_loop(device_loop)
     rg.set_index_buffer(index_buffer)
+    if icp_loop:
+        rg.set_icp_loop(True)
     statuses = []
     for f, (d, c) in enumerate(seq):
         st_ref = ref.step(d, c)
@@ -64,6 +67,8 @@ def run_pair(pkg, orc, synth, n, m, frames, N_prim, planes_at, device_loop=True,
     R, t = rg.pose()
     assert np.abs(np.array(t) - tg).max() < 5e-3
     assert np.abs(np.array(R).reshape(3, 3).T - Rg).max() < 5e-3
+    if icp_loop:
+        assert rg.icp_loop_faults() == 0
     rg.close()
     ref.close()
 
@@ -92,6 +97,13 @@ def test_loop_small_host_solve_and_index_buffer(pkg, orc, synth):
 def test_loop_640x480(pkg, orc, synth, fused):
     """Config 2 shape: TUM fr1/xyz-like 640x480 sequence, 3 planes of 1024x1024 Bump cells."""
     run_pair(pkg, orc, synth, 480, 640, frames=5, N_prim=1024, planes_at=1, fused=fused, noise=0.001 if fused else 0.0)
+
+
+@pytest.mark.parametrize("shape,N_prim,noise", [((120, 160), 512, 0.001), ((93, 131), 256, 0.0), ((480, 640), 1024, 0.001)])
+def test_loop_persistent_icp_kernel(pkg, orc, synth, shape, N_prim, noise):
+    """rgbdslam_set_icp_loop: the whole coarse-to-fine Gauss-Newton loop in one persistent launch (epoch word
+    between iterations instead of kernel boundaries) gives the oracle's bits, without a single give-up."""
+    run_pair(pkg, orc, synth, shape[0], shape[1], frames=6, N_prim=N_prim, planes_at=1, noise=noise, icp_loop=True)
 
 
 def test_loop_noisy(pkg, orc, synth):
