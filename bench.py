@@ -147,7 +147,9 @@ def main():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--kernel", default="k_icp_iter", help="kernel whose roofline is reported")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--icp-loop", type=int, default=0, help="1: persistent-loop ICP (rgbdslam_set_icp_loop)")
+    ap.add_argument("--icp-loop", type=int, default=1,
+                    help="1 (default): persistent-loop ICP, one launch per frame (rgbdslam_set_icp_loop: this process owns the GPU "
+                         "and uses one stream, which is how bench.py runs); 0: twelve k_icp_iter launches per frame")
     ap.add_argument("--no-large-kernels", action="store_true", help="skip the config-3/config-4-size kernel rooflines")
     ap.add_argument("--profile-in-timed-region", action="store_true",
                     help="record the roofline events inside the timed region instead of in a second pass")
@@ -197,9 +199,12 @@ def main():
     ctx = C.c_void_p(host.slamhost_rg_ctx(rg._h))
     eq, centers = synth.plane_equations()
     if args.icp_loop:
-        rg.set_icp_loop(True)
-        if args.kernel == "k_icp_iter":
-            args.kernel = "k_icp_loop"
+        try:
+            rg.set_icp_loop(True)
+        except RuntimeError:                 # the device cannot hold the loop kernel's grid: multi-launch path
+            args.icp_loop = 0
+    if args.kernel == "k_icp_iter" and args.icp_loop:
+        args.kernel = "k_icp_loop"
 
     def run(frames):
         return rg.run_device_sequence([depth_dev[i] for i in frames], [bgr_dev[i] for i in frames])
@@ -233,6 +238,8 @@ def main():
         tr = torch.tensor([tracked], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tr, op=dist.ReduceOp.MIN)
         tracked = int(tr.item())
+    if args.icp_loop and rg.icp_loop_faults():
+        raise SystemExit("the persistent ICP kernel gave up waiting for its grid (is another process using this GPU?): result invalid")
     if tracked != args.steps:
         raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
 
@@ -296,7 +303,8 @@ def main():
                "config": {"workload": "TUM fr1/xyz-shaped %dx%d RGB-D sequence (synthetic room corner, 1 mm depth noise), 3-level ICP "
                                       "(<= 3/4/5 iterations) + prediction + merge + Bump fusion into 3 planes of 1024x1024"
                                       % (m, n),
-                          "sequences": world, "frames_resident_in_hbm": True},
+                          "sequences": world, "frames_resident_in_hbm": True,
+                          "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame"},
                "roofline": roofline, "cpu_baseline": cpu, "hbm_bound_kernels": large}
         print(json.dumps(out), flush=True)
     rg.close()
