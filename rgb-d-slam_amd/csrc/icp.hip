@@ -501,6 +501,9 @@ struct IcpLoopArgs {
     int nsteps;
     unsigned int epoch_base;
     int timeout_ticks;
+#ifdef ICP_LOOP_TIMING
+    long long *timing;                               // debug build only: 8 time stamps per step (rgbdslam_debug_icp_timing)
+#endif
 };
 
 __global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(4)))
@@ -540,6 +543,9 @@ void k_icp_loop(IcpLoopArgs L) {
             const int start = ICP_LV(start);
             a.iter = s - start;
             a.thr_alpha = L.thr_alpha; a.thr_tr = L.thr_tr; a.trace = nullptr; a.timing = nullptr;
+#ifdef ICP_LOOP_TIMING
+            if (L.timing) a.timing = L.timing + 8 * s;
+#endif
             a.first_launch = (s == 0); a.final_launch = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) a.intr4[k] = L.intr4[k];
@@ -1097,6 +1103,9 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
         ctx->icp_epoch_base += 4096u;                          // > any step index: a stale word never releases a waiter
         L.epoch_base = ctx->icp_epoch_base;
         L.timeout_ticks = 5000000;                             // 50 ms of the 100 MHz wall clock
+#ifdef ICP_LOOP_TIMING
+        L.timing = ctx->icp_timing_dev;
+#endif
         KLAUNCH(ctx, k_icp_loop, dim3(ICP_CHAINS), dim3(64 * ICP_MAX_WAVES), L);
         HIP_TRY(hipGetLastError());
         return 0;
