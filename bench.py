@@ -166,6 +166,8 @@ def main():
     backend = os.environ.get("RGBDSLAM_BENCH_BACKEND", "nccl")
     if "RGBDSLAM_BENCH_DEVICE" in os.environ:
         local = int(os.environ["RGBDSLAM_BENCH_DEVICE"])
+        if world > 1:
+            args.icp_loop = 0          # ranks share one card: the persistent kernel needs the GPU to itself
     torch.cuda.set_device(local)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
@@ -255,8 +257,15 @@ def main():
     lib.rgbdslam_profile_kernel(ctx, None)
     per_frame_launches = launches.value / float(args.steps)
     bytes_per_frame = algo_bytes(args.kernel, n, m, level_iters)
-    avg_ms = tot_ms.value / max(1, launches.value)
-    achieved = bytes_per_frame * args.steps / (tot_ms.value * 1e-3) / 1e9 if tot_ms.value > 0 else 0.0
+    # every event pair carries the markers' own processing time on top of what it brackets: measured with empty
+    # pairs on the same stream and taken off (one pair per frame: the pair around the loop kernel, or around the
+    # twelve back-to-back k_icp_iter launches)
+    ev_ms = C.c_double()
+    lib.rgbdslam_profile_event_overhead(ctx, 200, C.byref(ev_ms))
+    pairs = args.steps if args.kernel in ("k_icp_iter", "k_icp_loop") else launches.value
+    net_ms = max(0.0, tot_ms.value - pairs * ev_ms.value)
+    avg_ms = net_ms / max(1, launches.value)
+    achieved = bytes_per_frame * args.steps / (net_ms * 1e-3) / 1e9 if net_ms > 0 else 0.0
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of
     # their own, profiles/*_pmc_traffic.json): counters cannot be read from inside this process
     traffic = None
@@ -271,6 +280,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(bytes_per_frame / max(1.0, per_frame_launches)),
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_frame": round(per_frame_launches, 2),
+                "event_pair_us": round(tot_ms.value / max(1, pairs) * 1e3, 2), "empty_event_pair_us": round(ev_ms.value * 1e3, 2),
                 "algorithmic_bytes_per_frame": bytes_per_frame, "icp_iterations_per_level": level_iters}
 
     # ---- CPU baseline: the oracle's display() loop on a bounded sample of the same sequence ----

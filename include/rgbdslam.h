@@ -49,6 +49,8 @@ const char *rgbdslam_version(void);
  * profile_read synchronises, returns the summed durations and the launch count, and resets. */
 int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_name);
 int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *launches);
+/* mean elapsed time of `pairs` event pairs with nothing between their two records (the markers' own cost) */
+int rgbdslam_profile_event_overhead(rgbdslam_ctx *ctx, int pairs, double *mean_ms);
 /* Debug: int64[7] device words that receive wall_clock64 stamps (10 ns ticks) of the phases of the
  * last ICP iteration kernel: [0] first workgroup start, [1..6] the tail workgroup's start, rounds
  * done, chain sums published, arrival counted, tree done, solve done.  NULL switches it off. */

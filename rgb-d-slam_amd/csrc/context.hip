@@ -132,6 +132,29 @@ extern "C" int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *l
     return 0;
 }
 
+// What an event pair measures with NOTHING between its two records, on the context's stream: the marker's own
+// processing time, which every bracketed launch carries on top of the kernel's duration.
+extern "C" int rgbdslam_profile_event_overhead(rgbdslam_ctx *ctx, int pairs, double *mean_ms) {
+    if (!ctx || !mean_ms || pairs <= 0 || pairs > 4096) return RGBDSLAM_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double tot = 0.0;
+    for (int k = 0; k < pairs; k++) {
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_ms = tot / pairs;
+    return 0;
+}
+
 // debug: 7 x int64 device words receiving phase time stamps of the LAST k_icp_iter launch
 extern "C" int rgbdslam_debug_icp_timing(rgbdslam_ctx *ctx, long long *timing7_dev) {
     if (!ctx) return RGBDSLAM_E_ARG;
