@@ -135,6 +135,25 @@ class Context:
             C.c_size_t(pitch), _ptr(vprev), _ptr(nprev), _ptr(rgbd_prev), n, m, _ptr(pose_state), _ptr(status),
             _ptr(trace)), "align_gauss_newton")
 
+    def track_frame(self, prm, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, n, m, pose_block, history, frame_index,
+                    pitch=None):
+        """rgbdslam_track_frame: AlignFrameGaussNewton + the pose algebra of display() on a device-resident pose block
+        (43 words: pose_state 24, status 4 ... see include/rgbdslam.h); history = f32[frames][16] or None."""
+        pitch = pitch or 4 * m
+        _chk(self.lib.rgbdslam_track_frame(
+            self._h, C.byref(prm), _ptr(vmap), _ptr(nmap), _ptr(rgb), _ptr(gx), C.c_size_t(pitch), _ptr(gy),
+            C.c_size_t(pitch), _ptr(vprev), _ptr(nprev), _ptr(rgbd_prev), n, m, _ptr(pose_block), _ptr(history),
+            int(frame_index)), "track_frame")
+
+    def set_icp_loop(self, on):
+        """Persistent-loop mode of track_frame (one launch per frame); raises when the device cannot hold the grid."""
+        _chk(self.lib.rgbdslam_set_icp_loop(self._h, int(on)), "set_icp_loop")
+
+    def icp_loop_faults(self):
+        f = C.c_int(0)
+        _chk(self.lib.rgbdslam_icp_loop_faults(self._h, C.byref(f)), "icp_loop_faults")
+        return f.value
+
     # -- stage 4 --
     def merge_depth_off(self, rgbd, depth, pitch, rgb, mask, n, m):
         _chk(self.lib.rgbdslam_merge_depth_off(self._h, _ptr(rgbd), _ptr(depth), C.c_size_t(pitch), _ptr(rgb), _ptr(mask), n, m),

@@ -181,6 +181,72 @@ def test_align_track_loss(ctx, pkg, orc, pair):
     assert not ok
 
 
+def _pose_block(torch, I, z):
+    """rgbdslam_pose_block as 76 float words: pose_state(24) status(4, int32 bits) P_rel P_rel_inv P_glob."""
+    pb = torch.zeros(24 + 4 + 48, dtype=torch.float32, device="cuda")
+    pb[:24] = torch.from_numpy(np.concatenate([I, z, I, z]).astype(np.float32)).cuda()
+    return pb
+
+
+@pytest.mark.parametrize("case", ["default", "two_levels", "one_level", "no_extra_iterations", "many_iterations", "never_converges",
+                                  "singular", "two_frames"])
+def test_track_frame_persistent_loop_equals_multi_launch(ctx, pkg, orc, pair, case):
+    """rgbdslam_set_icp_loop: one persistent launch per frame must leave the pose block and the history row of the
+    one-launch-per-iteration path bit for bit -- level counts below 3, max_iter 0 (two steps per level), many steps,
+    thresholds that never converge (every step executes), a singular system (the solve fails at the first step and
+    the loop ends from there), and two frames in a row (epoch base moves on, nothing is cleared in between).  The
+    default case is also checked against the oracle's AlignFrameGaussNewton."""
+    n, m = 480, 640
+    gr, gc = orc.icp_grid(n, m, 1)
+    ctx.alloc_buffers(gr, gc)
+    I = np.eye(3, dtype=np.float32).reshape(-1)
+    z = np.zeros(3, np.float32)
+    prm = pkg.icp_params()
+    if case == "two_levels":
+        prm.lvl = 2
+    elif case == "one_level":
+        prm.lvl = 1
+    elif case == "no_extra_iterations":
+        prm.max_iter[0] = prm.max_iter[1] = prm.max_iter[2] = 0
+    elif case == "many_iterations":
+        prm.max_iter[0], prm.max_iter[1], prm.max_iter[2] = 9, 7, 8
+    elif case == "never_converges":
+        prm.thres_cvg_alpha = prm.thres_cvg_tr = 0.0
+    cur = [dev(pair[k]) for k in ("v1", "n1", "rgb1", "gx1", "gy1")]
+    if case == "singular":
+        empty = torch.zeros(n, m, 3, device="cuda")
+        cur[0] = cur[1] = cur[2] = empty
+    prev = [dev(pair[k]) for k in ("v0", "n0", "rgbd0")]
+    frames = 2 if case == "two_frames" else 1
+    out = []
+    for loop in (False, True):
+        ctx.set_icp_loop(loop)
+        pb = _pose_block(torch, I, z)
+        hist = torch.zeros(4, 16, device="cuda")
+        for f in range(frames):
+            ctx.track_frame(prm, *cur, *prev, n, m, pb, hist, f)
+        ctx.synchronize()
+        if loop:
+            assert ctx.icp_loop_faults() == 0
+        out.append((host(pb).copy(), host(hist).copy()))
+    ctx.set_icp_loop(False)
+    same(out[1][0].view(np.int32), out[0][0].view(np.int32))
+    same(out[1][1].view(np.int32), out[0][1].view(np.int32))
+    status = out[1][0].view(np.int32)[24:28]
+    if case == "singular":
+        assert status[0] == 0 and status[1] == 0
+    else:
+        assert status[0] == 1 and status[3] == frames
+    if case == "never_converges":
+        assert status[1] == sum(prm.max_iter[k] + 2 for k in range(3))
+    if case == "default":
+        ok, R, t, tr = orc.align_gauss_newton(orc.icp_params(), pair["calib"][:4], pair["v1"], pair["n1"], pair["rgb1"], pair["v0"],
+                                              pair["n0"], pair["rgbd0"], I, z, I, z)
+        assert ok and status[1] == len(tr)
+        same(out[1][0][:9], R)
+        same(out[1][0][9:12], t)
+
+
 def test_merge_and_model_maps(ctx, orc, pair, synth):
     n, m = 480, 640
     calib = pair["calib"]

@@ -110,8 +110,8 @@ def test_loop_noisy(pkg, orc, synth):
     run_pair(pkg, orc, synth, 120, 160, frames=5, N_prim=512, planes_at=1, noise=0.001)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_loop_track_loss_reseeds_model(pkg, orc, synth, fused):
+@pytest.mark.parametrize("fused,icp_loop", [(True, False), (False, False), (True, True)])
+def test_loop_track_loss_reseeds_model(pkg, orc, synth, fused, icp_loop):
     """A frame from a far-away pose must report lost (RG.cpp:910-920), keep the pose and re-seed the
     model from the input frame (GP-demo.cpp:189-196).  In the fused pipeline that decision is taken
     on the device (kernels gated on the pose block)."""
@@ -120,6 +120,8 @@ def test_loop_track_loss_reseeds_model(pkg, orc, synth, fused):
     ref = orc.Slam(n, m, calib, N_prim=256, M_prim=256)
     rg = pkg.RG(n, m, calib, N_prim=256, M_prim=256)
     rg.set_fused(fused)
+    if icp_loop:
+        rg.set_icp_loop(True)
     far = synth.euler_xyz(*np.deg2rad([14.0, -12.0, 9.0]))
     frames = [synth.render(np.eye(3), np.zeros(3), n, m, calib), synth.render(far, np.array([0.35, -0.3, 0.25]), n, m, calib),
               synth.render(far, np.array([0.35, -0.3, 0.25]), n, m, calib)]
@@ -135,6 +137,8 @@ def test_loop_track_loss_reseeds_model(pkg, orc, synth, fused):
     same(np.array(t, np.float32), tr, "poset")
     for name in ("VMap", "NMap", "RGBD", "Mask"):
         same(rg.buffer(name), ref.buffer(name), name)
+    if icp_loop:
+        assert rg.icp_loop_faults() == 0
     rg.close()
     ref.close()
 
@@ -184,8 +188,8 @@ def test_hip_detection_reproduces_golden_fixture(pkg):
     rg.close()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth, overlap):
+@pytest.mark.parametrize("overlap,icp_loop", [(False, False), (True, False), (False, True)])
+def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth, overlap, icp_loop):
     """run_device_sequence enqueues every frame without a host sync (pose history on the device);
     the per-frame poses and the final model must equal the oracle's frame-by-frame loop, including
     a tracking loss in the middle of the sequence."""
@@ -198,6 +202,8 @@ def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth, overlap):
     ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
     rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
     rg.set_overlap(overlap)
+    if icp_loop:
+        rg.set_icp_loop(True)
     ref.step(*seq[0]); rg.load_frame(*seq[0]); rg.step()
     ref.set_planes(eq, centers); rg.set_planes(eq, centers)
     want = []
@@ -216,6 +222,8 @@ def test_async_sequence_matches_stepwise_oracle(pkg, orc, synth, overlap):
         same(hist[k, 9:12], t, "frame %d poset" % (k + 1))
     for name in ("VMap", "NMap", "RGBD", "Mask", "Label", "Maskb0", "Bump1", "RGBb2"):
         same(rg.buffer(name), ref.buffer(name), name)
+    if icp_loop:
+        assert rg.icp_loop_faults() == 0
     rg.close()
     ref.close()
 
