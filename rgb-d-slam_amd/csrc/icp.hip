@@ -220,8 +220,14 @@ struct IcpIterArgs {
 // determinant test, thread 0 the Cholesky solve and the pose update.  st = working copy of the state
 // (LDS), out = device-resident state it is committed to, sh = 2 floats of LDS.
 struct IcpEndArgs { float *pose_state; int32_t *status; rgbdslam_pose_block *pb; float *history; int frame_index; };
-// persistent loop: epoch word = base + index of the next step that executes (>= nsteps: finished)
-struct IcpLoopCtl { unsigned int *epoch; unsigned int base; int step, next_level, nsteps; };
+// persistent loop: the tail publishes the state in ONE 128-byte line: 25 data words (Rinv 9, tinv 3, Rcurr 9, tcurr 3,
+// flags = lvl_iters | cvg << 24 | fail << 25) in slots k + k/7, and the epoch word = base + index of the next step
+// that executes (>= nsteps: finished) in the last slot of each 32-byte sector (slots 7, 15, 23, 31), stored after
+// the data has landed.  A reader takes the line with one wave-wide load and accepts it when all four copies
+// carry the new epoch: whatever way the memory system splits the line, every piece was then read after the data.
+struct IcpLoopCtl { unsigned int *pub; unsigned int base; int step, next_level, nsteps; };
+#define ICP_PUB_DATA 25
+__device__ __forceinline__ constexpr int icp_pub_slot(int k) { return k + k / 7; }
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
                                                bool with_end, IcpEndArgs end, IcpLoopCtl lc);
@@ -254,6 +260,25 @@ struct IcpShared {
 // persistent loop: the model pixels a wave samples in its first two rounds are the same for every iteration of a
 // level (only the pose changes), so they stay in registers from one step to the next
 struct IcpModelCache { IcpModelPx r0, r1; int lvl; };
+// Every vector-memory store this wave has issued is acknowledged (agent-scope stores: at the device's coherence
+// point) before anything that follows is issued.  Part of the release ordering between the write-through stores
+// and the arrival counter / epoch that announces them.
+__device__ __forceinline__ void icp_wait_stores() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// field-by-field copy: a struct assignment is one memcpy, and when the optimiser cannot split it the private copy
+// ends up in scratch -- or is "promoted" to LDS, which costs a read of the dispatch packet per launch
+__device__ __forceinline__ void icp_state_copy(IcpState *d, const IcpState *s) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { d->Rinv[k] = s->Rinv[k]; d->Rcurr[k] = s->Rcurr[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { d->tinv[k] = s->tinv[k]; d->tcurr[k] = s->tcurr[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d->intr[k] = s->intr[k];
+    d->cvg = s->cvg; d->fail = s->fail; d->iters = s->iters; d->lvl_iters = s->lvl_iters;
+}
+
 template <bool LOOP>
 __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpShared &S, IcpLoopCtl lc, const int tid, const int t,
                                               IcpModelCache &mc) {
@@ -292,12 +317,11 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         float *dst = (float *)&sst;
         if (a.state) {
             const float *src = (const float *)a.state;
-            if (a.pose_state && lane < 24) spose[lane] = a.pose_state[lane];
+            // persistent loop after step 0: the hand-over at the end of the previous step left the published state in
+            // sst, and spose is the kernel prologue's
+            if ((!LOOP || a.first_launch) && a.pose_state && lane < 24) spose[lane] = a.pose_state[lane];
             if (!a.first_launch) {
-                if (LOOP) {
-                    if (lane < (int)(sizeof(IcpState) / 4))
-                        dst[lane] = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
+                if (!LOOP && lane < (int)(sizeof(IcpState) / 4)) dst[lane] = src[lane];
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -382,11 +406,12 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     }
     long long ts1 = a.timing ? wall_clock64() : 0;
     // Publish the chain sums to the other XCDs without a full L2 write-back: agent-scope atomic
-    // stores are written through, the workgroup-scope release only waits for them to complete, and
+    // stores are written through, icp_wait_stores() waits until they are acknowledged at that scope (an agent-scope
+    // release fence would add the write-back of the whole L2, a workgroup-scope one emits no wait at all here), and
     // the last workgroup reads them back with agent-scope atomic loads (each XCD has its own L2).
     if (wave == 0 && lane < 27)
         __hip_atomic_store(a.chains + lane * ICP_CHAINS + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    icp_wait_stores();
     __syncthreads();
     long long ts2 = a.timing ? wall_clock64() : 0;
     // Two-level arrival counter (same-address device-scope atomics serialise at the memory side):
@@ -447,7 +472,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         if (LOOP) __hip_atomic_store(a.ticket + 32 * tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else a.ticket[32 * tid] = 0u;
     }
-    if (LOOP) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the resets have landed before the epoch moves
+    if (LOOP) icp_wait_stores();                       // the resets have landed before the epoch moves
     __syncthreads();
     if (a.do_solve) {
         IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
@@ -484,8 +509,10 @@ struct IcpLoopLevel { int start, grid_rows, grid_cols, lvl, max_iter; };
 #define ICP_OFF_TICKET (27 * ICP_CHAINS * 4)
 #define ICP_OFF_OUT (ICP_OFF_TICKET + ICP_TICKET_WORDS * 4)
 #define ICP_OFF_STATE (ICP_OFF_OUT + 128)
-#define ICP_OFF_EPOCH (ICP_OFF_STATE + 128)      // epoch word; fault flag 128 bytes further
-#define ICP_BLOCK_BYTES (ICP_OFF_EPOCH + 256)
+#define ICP_OFF_EPOCH (ICP_OFF_STATE + 128)      // fault flag of k_icp_loop at + 128
+#define ICP_OFF_PUB (ICP_OFF_EPOCH + 256)        // published loop state: one 128-byte line
+#define ICP_BLOCK_BYTES (ICP_OFF_PUB + 128)
+static_assert(ICP_OFF_PUB % 128 == 0 && offsetof(IcpState, tcurr) == 21 * 4, "published state layout");
 static_assert(sizeof(IcpState) <= 128, "state slot");
 struct IcpLoopArgs {
     const float *VMap, *NMap, *RGB, *Gx, *Gy, *VMap_prev, *NMap_prev, *RGBD_prev;
@@ -511,10 +538,14 @@ void k_icp_loop(IcpLoopArgs L) {
     ICP_SHARED_DECL(S);
     __shared__ int next_step;
     const int t = blockIdx.x;
-    unsigned int *const epoch = (unsigned int *)(L.block + ICP_OFF_EPOCH);
+    unsigned int *const pub = (unsigned int *)(L.block + ICP_OFF_PUB);
     int s = 0;
     IcpModelCache mc;
     mc.lvl = -1;
+    // what no later step refreshes: the pose pair of the frame and the intrinsics (a workgroup whose chain does not
+    // exist at the coarsest level never runs step 0's begin)
+    if (threadIdx.x < 24) spose_[threadIdx.x] = L.pb->pose_state[threadIdx.x];
+    else if (threadIdx.x >= 32 && threadIdx.x < 36) sst_.intr[threadIdx.x - 32] = L.intr4[threadIdx.x - 32];
     for (;;) {
         // the level's constants are picked with uniform selects (a dynamically indexed kernarg array would be
         // copied to scratch memory and turn every one of them into a vector register)
@@ -551,26 +582,39 @@ void k_icp_loop(IcpLoopArgs L) {
             for (int k = 0; k < 4; k++) a.intr4[k] = L.intr4[k];
             a.pose_state_rw = L.pb->pose_state; a.status = L.pb->status; a.pb = L.pb; a.history = L.history;
             a.frame_index = L.frame_index;
-            icp_iter_body<true>(a, S, IcpLoopCtl{epoch, L.epoch_base, s, start + a.max_iter + 2, L.nsteps}, tid, t, mc);
+            icp_iter_body<true>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps}, tid, t, mc);
         }
 #undef ICP_LV
         __syncthreads();                               // every thread is done with S
-        if (threadIdx.x == 0) {
+        if (tid < 64) {                                // wave 0 polls the published line, one word per lane
             const long long t0 = wall_clock64();
             int nxt;
+            unsigned int w = 0;
             for (;;) {
-                const unsigned int e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int d = (int)(e - L.epoch_base);
-                if (d > s) { nxt = d; break; }
+                w = __hip_atomic_load(pub + (tid & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int e0 = __builtin_amdgcn_readlane(w, 7), e1 = __builtin_amdgcn_readlane(w, 15),
+                                   e2 = __builtin_amdgcn_readlane(w, 23), e3 = __builtin_amdgcn_readlane(w, 31);
+                const int d = (int)(e0 - L.epoch_base);
+                if (d > s && e1 == e0 && e2 == e0 && e3 == e0) { nxt = d; break; }
                 if (wall_clock64() - t0 > (long long)L.timeout_ticks) { nxt = -1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            next_step = nxt;
+            if (nxt >= 0 && tid < 32 && (tid & 7) != 7) {
+                const int k = tid - (tid >> 3);        // inverse of icp_pub_slot
+                float *dst = (float *)&sst_;           // Rinv, tinv, Rcurr, tcurr are the first 24 words of IcpState
+                if (k < 24) dst[k] = __uint_as_float(w);
+                else if (k == 24) {
+                    const int li = (int)(w & 0xffffff);
+                    sst_.lvl_iters = li; sst_.iters = (li & 255) + ((li >> 8) & 255) + ((li >> 16) & 255);
+                    sst_.cvg = (w >> 24) & 1; sst_.fail = (w >> 25) & 1;
+                }
+            }
+            if (tid == 0) next_step = nxt;
         }
         __syncthreads();
         const int nxt = next_step;
         if (nxt < 0) {                                 // broken residency assumption: report and leave
-            if (threadIdx.x == 0) {
+            if (tid == 0) {
                 __hip_atomic_store((int *)(L.block + ICP_OFF_EPOCH + 128), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (t == 0) L.pb->status[0] = 0;
             }
@@ -785,38 +829,47 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         llt_fail = llt_solve6_reg(sums, x);                    // RG.cpp:873
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    IcpState loc = *st;
-    float det = sh[0];
-    if ((double)__builtin_fabsf(det) < 1e-15 || det != det || llt_fail) {   // RG.cpp:864-871
-        loc.fail = 1;
-    } else {
-        if (trace) {
-            float *tr = trace + 33 * loc.iters;
-            for (int k = 0; k < 27; k++) tr[k] = sums[k];
-            for (int k = 0; k < 6; k++) tr[27 + k] = x[k];
+    if (lc.pub ? wave != 0 : threadIdx.x != 0) return;
+    IcpState loc;
+    int nxt = 0;
+    if (threadIdx.x == 0) {
+        icp_state_copy(&loc, st);
+        float det = sh[0];
+        if ((double)__builtin_fabsf(det) < 1e-15 || det != det || llt_fail) {   // RG.cpp:864-871
+            loc.fail = 1;
+        } else {
+            if (trace) {
+                float *tr = trace + 33 * loc.iters;
+                for (int k = 0; k < 27; k++) tr[k] = sums[k];
+                for (int k = 0; k < 6; k++) tr[27 + k] = x[k];
+            }
+            icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
         }
-        icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
+        if (lc.pub) {
+            // persistent loop: a failed solve ends the loop, a converged level continues at the next level
+            nxt = loc.fail ? lc.nsteps : (loc.cvg ? lc.next_level : lc.step + 1);
+            icp_state_copy(st, &loc);                          // LDS: the publishing lanes pick their words up from here
+        }
     }
-    if (lc.epoch) {
-        // persistent loop: the state is committed with write-through stores, then the epoch names the next
-        // step that executes (a failed solve ends the loop, a converged level continues at the next level)
-        const int nxt = loc.fail ? lc.nsteps : (loc.cvg ? lc.next_level : lc.step + 1);
-#define ICP_PUB(dst, v) __hip_atomic_store(&(dst), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#pragma unroll
-        for (int k = 0; k < 9; k++) { ICP_PUB(out->Rinv[k], loc.Rinv[k]); ICP_PUB(out->Rcurr[k], loc.Rcurr[k]); }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { ICP_PUB(out->tinv[k], loc.tinv[k]); ICP_PUB(out->tcurr[k], loc.tcurr[k]); }
-#pragma unroll
-        for (int k = 0; k < 4; k++) ICP_PUB(out->intr[k], loc.intr[k]);
-        ICP_PUB(out->cvg, loc.cvg); ICP_PUB(out->fail, loc.fail); ICP_PUB(out->iters, loc.iters); ICP_PUB(out->lvl_iters, loc.lvl_iters);
-#undef ICP_PUB
-        if (nxt >= lc.nsteps) icp_end_step(&loc, end);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __hip_atomic_store(lc.epoch, lc.base + (unsigned int)nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lc.pub) {
+        // ONE wave-wide store publishes the line (a single 128-byte write instead of 25 word stores to a line that 512
+        // workgroups are polling: those were acknowledged slowly and the ordering fence waited for them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nxt = __builtin_amdgcn_readfirstlane(nxt);
+        if (lane < 32) {
+            const int k = lane - (lane >> 3);                  // inverse of icp_pub_slot
+            unsigned int word = ((const unsigned int *)st)[k < 24 ? k : 0];
+            if (k == 24)
+                word = (unsigned int)(st->lvl_iters & 0xffffff) | ((unsigned int)(st->cvg != 0) << 24) | ((unsigned int)(st->fail != 0) << 25);
+            if ((lane & 7) == 7) word = lc.base + (unsigned int)nxt;
+            __hip_atomic_store(lc.pub + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x == 0 && nxt >= lc.nsteps) icp_end_step(&loc, end);
         return;
     }
-    *out = loc;
+    icp_state_copy(out, &loc);
     if (with_end) icp_end_step(&loc, end);
 }
 
