@@ -9,7 +9,11 @@
 // (D1/ICP.cu:50-70): the 27 sums are bit-identical to a serial restatement of the reference.
 #include "common.hpp"
 
-#define ICP_MAX_WAVES 5   // waves (= 8x8 blocks in flight) per workgroup: 640x480 has 9.4 blocks per chain -> two balanced rounds
+#define ICP_CHAIN_WAVES 5  // waves (= 8x8 blocks in flight) per chain: 640x480 has 9.4 blocks per chain -> two balanced rounds
+#define ICP_WG_CHAINS 2    // a workgroup owns chains t and t+256 and adds their sums itself (first level of reduce<512>):
+                           // half as many sums to publish, to count and -- the expensive part -- to read back in the tail
+#define ICP_MAX_WAVES (ICP_CHAIN_WAVES * ICP_WG_CHAINS)
+#define ICP_WGS (ICP_CHAINS / ICP_WG_CHAINS)
 #define ICP_TAIL_TERMS ((27 + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES)   // terms per wave in the tail
 #define ICP_TICKET_GROUP 16
 #define ICP_TICKET_WORDS (32 * (1 + 512 / ICP_TICKET_GROUP))
@@ -291,8 +295,11 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     int &last_flag = S.last_flag;
     const int wave = tid >> 6, lane = tid & 63;
     const int nblk = a.rows_local * a.grid_cols;
-    const int chain_len = (nblk - t + ICP_CHAINS - 1) / ICP_CHAINS;
-    const int rounds = (chain_len + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES;
+    const int nwg = min(a.nchain, ICP_WGS);             // workgroups of this launch / step
+    const int half = wave / ICP_CHAIN_WAVES, wv = wave - half * ICP_CHAIN_WAVES;   // chain of this wave: t + 256 * half
+    const int tc = t + ICP_WGS * half;
+    const int chain_len = max(0, (nblk - tc + ICP_CHAINS - 1) / ICP_CHAINS);
+    const int rounds = ((nblk - t + ICP_CHAINS - 1) / ICP_CHAINS + ICP_CHAIN_WAVES - 1) / ICP_CHAIN_WAVES;   // of the longer chain, t
     long long ts0 = a.timing ? wall_clock64() : 0;
     if (a.timing && t == 0 && tid == 0) a.timing[0] = ts0;
 
@@ -335,12 +342,12 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             else if (lane == 16) { sst.cvg = 0; sst.fail = 0; }
         }
     }
-    int k = wave;
+    int k = wv;
     bool active = k < chain_len, inside = false;
     size_t idx = 0;
     IcpModelPx mp;
     auto locate = [&](int kk) {
-        int blk = t + ICP_CHAINS * kk;                // band-local block number, blk = brow + bcol*rows (ICP.cu:238)
+        int blk = tc + ICP_CHAINS * kk;                // band-local block number, blk = brow + bcol*rows (ICP.cu:238)
         int br = a.br_lo + blk % a.rows_local, bc = blk / a.rows_local;
         int i = br * 8 + (lane >> 3), j = bc * 8 + (lane & 7);
         inside = (i * a.fact < a.n && j * a.fact < a.m);
@@ -348,7 +355,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     };
     if (LOOP) {
         if (mc.lvl != a.lvl) {                        // first step of a level: both rounds' pixels are requested at once
-            if (wave + ICP_MAX_WAVES < chain_len) { locate(wave + ICP_MAX_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+            if (wv + ICP_CHAIN_WAVES < chain_len) { locate(wv + ICP_CHAIN_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
             if (active) { locate(k); mc.r0 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
             mc.lvl = a.lvl;
         } else if (active) locate(k);
@@ -366,7 +373,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     float acc = 0.0f;                                 // wave 0, lanes 0..26: running chain sum (ICP.cu:56-58)
     for (int r = 0; r < rounds; r++) {
         if (r > 0) {
-            k = r * ICP_MAX_WAVES + wave;
+            k = r * ICP_CHAIN_WAVES + wv;
             active = k < chain_len;
             if (active) {
                 locate(k);
@@ -398,9 +405,9 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             if (lane < 27) part[wave][lane] = sum;
         }
         __syncthreads();
-        if (wave == 0 && lane < 27) {
-            int cnt = min(ICP_MAX_WAVES, chain_len - r * ICP_MAX_WAVES);
-            for (int w = 0; w < cnt; w++) acc += part[w][lane];
+        if (wv == 0 && lane < 27) {                   // waves 0 and 5: one chain each
+            int cnt = min(ICP_CHAIN_WAVES, chain_len - r * ICP_CHAIN_WAVES);
+            for (int w = 0; w < cnt; w++) acc += part[wave + w][lane];
         }
         __syncthreads();
     }
@@ -409,8 +416,12 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     // stores are written through, icp_wait_stores() waits until they are acknowledged at that scope (an agent-scope
     // release fence would add the write-back of the whole L2, a workgroup-scope one emits no wait at all here), and
     // the last workgroup reads them back with agent-scope atomic loads (each XCD has its own L2).
+    // offset 256 of reduce<512> (ICP.cu:35): chain t + chain t+256, added here instead of in the tail (a chain that does
+    // not exist contributes the 0 the reference's memset leaves in its place)
+    if (wave == ICP_CHAIN_WAVES && lane < 27) part[ICP_CHAIN_WAVES][lane] = acc;
+    __syncthreads();
     if (wave == 0 && lane < 27)
-        __hip_atomic_store(a.chains + lane * ICP_CHAINS + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.chains + lane * ICP_WGS + t, acc + part[ICP_CHAIN_WAVES][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     icp_wait_stores();
     __syncthreads();
     long long ts2 = a.timing ? wall_clock64() : 0;
@@ -418,8 +429,8 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     // 16 workgroups share a group counter on its own 128-byte line, the last arrival of a group
     // bumps the top counter, the last arrival there owns the tail.
     if (tid == 0) {
-        int g = t / ICP_TICKET_GROUP, ngroups = (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP;
-        unsigned int expect = (unsigned int)min(ICP_TICKET_GROUP, a.nchain - g * ICP_TICKET_GROUP);
+        int g = t / ICP_TICKET_GROUP, ngroups = (nwg + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP;
+        unsigned int expect = (unsigned int)min(ICP_TICKET_GROUP, nwg - g * ICP_TICKET_GROUP);
         unsigned int old = __hip_atomic_fetch_add(a.ticket + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int last = 0;
         if (old == expect - 1u) {
@@ -438,27 +449,25 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     // tail costs one memory round trip, not one per term.
     // The loads are unconditional (the buffer always holds 27 x 512 floats; out-of-range terms re-read term 26) and
     // the unused values are replaced by 0 afterwards: predicated loads made the compiler wait for memory between them.
-    float x[ICP_TAIL_TERMS][8];
+    float x[ICP_TAIL_TERMS][4];
 #pragma unroll
     for (int u = 0; u < ICP_TAIL_TERMS; u++) {
         const int term = min(wave + ICP_MAX_WAVES * u, 26);
 #pragma unroll
-        for (int qd = 0; qd < 8; qd++)
-            x[u][qd] = __hip_atomic_load(a.chains + term * ICP_CHAINS + lane + 64 * qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int qd = 0; qd < 4; qd++)
+            x[u][qd] = __hip_atomic_load(a.chains + term * ICP_WGS + lane + 64 * qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (a.nchain < ICP_CHAINS) {
+    if (nwg < ICP_WGS) {
 #pragma unroll
         for (int u = 0; u < ICP_TAIL_TERMS; u++)
 #pragma unroll
-            for (int qd = 0; qd < 8; qd++) x[u][qd] = (lane + 64 * qd < a.nchain) ? x[u][qd] : 0.0f;
+            for (int qd = 0; qd < 4; qd++) x[u][qd] = (lane + 64 * qd < nwg) ? x[u][qd] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < ICP_TAIL_TERMS; u++) {
         int term = wave + ICP_MAX_WAVES * u;
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++) x[u][qd] = x[u][qd] + x[u][qd + 4];
-        x[u][0] = x[u][0] + x[u][2]; x[u][1] = x[u][1] + x[u][3];
-        float s = x[u][0] + x[u][1];
+        x[u][0] = x[u][0] + x[u][2]; x[u][1] = x[u][1] + x[u][3];   // offset 128
+        float s = x[u][0] + x[u][1];                                 // offset 64
         s = s + __shfl_down(s, 32);
         s = s + __shfl_down(s, 16);
         s = s + __shfl_down(s, 8);
@@ -468,7 +477,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         if (lane == 0 && term < 27) { fin[term] = s; a.sums[term] = s; }
     }
     long long ts4 = a.timing ? wall_clock64() : 0;
-    if (tid <= (a.nchain + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) {   // ready for the next launch / step
+    if (tid <= (nwg + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) {   // ready for the next launch / step
         if (LOOP) __hip_atomic_store(a.ticket + 32 * tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else a.ticket[32 * tid] = 0u;
     }
@@ -557,7 +566,7 @@ void k_icp_loop(IcpLoopArgs L) {
 #define ICP_LV(f) (in2 ? L.lv[2].f : (in1 ? L.lv[1].f : L.lv[0].f))
         const int grid_rows = ICP_LV(grid_rows), grid_cols = ICP_LV(grid_cols);
         const int nchain = min(grid_rows * grid_cols, ICP_CHAINS);
-        if (t < nchain) {
+        if (t < min(nchain, ICP_WGS)) {
             IcpIterArgs a;
             a.intr = nullptr; a.R = nullptr; a.t = nullptr;
             a.VMap = L.VMap; a.NMap = L.NMap; a.RGB = L.RGB; a.Gx = L.Gx; a.Gy = L.Gy; a.gxp = L.gxp; a.gyp = L.gyp;
@@ -1005,7 +1014,7 @@ extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
     int per_cu = 0, cus = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_loop, 64 * ICP_MAX_WAVES, 0));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    if (cus <= 0 || (long)per_cu * cus < ICP_CHAINS) return RGBDSLAM_E_STATE;
+    if (cus <= 0 || (long)per_cu * cus < ICP_WGS) return RGBDSLAM_E_STATE;
     // The occupancy query packs waves freely over the four SIMDs of a CU; the dispatcher deals a workgroup's waves
     // to the SIMDs starting from the first one (measured: at 144 registers = 3 waves per SIMD only ONE 5-wave
     // workgroup was resident per CU and the loop starved), so SIMD 0 must have room for every workgroup's share.
@@ -1013,7 +1022,7 @@ extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
     HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_icp_loop));
     const int regs = ((fa.numRegs > 0 ? fa.numRegs : 512) + 7) & ~7;
     const int waves_per_simd = 512 / regs < 8 ? 512 / regs : 8;
-    const int wgs_per_cu = (ICP_CHAINS + cus - 1) / cus;
+    const int wgs_per_cu = (ICP_WGS + cus - 1) / cus;
     if (wgs_per_cu * ((ICP_MAX_WAVES + 3) / 4) > waves_per_simd) return RGBDSLAM_E_STATE;
     ctx->icp_loop = 1;
     return 0;
@@ -1075,7 +1084,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     for (int k = 0; k < 4; k++) a.intr4[k] = ctx->calib.v[k];
     a.pose_state_rw = end ? end->pose_state : nullptr; a.status = end ? end->status : nullptr;
     a.pb = end ? end->pb : nullptr; a.history = end ? end->history : nullptr; a.frame_index = end ? end->frame_index : 0;
-    KLAUNCH(ctx, k_icp_iter, dim3(a.nchain), dim3(64 * a.nwaves), a);
+    KLAUNCH(ctx, k_icp_iter, dim3(a.nchain < ICP_WGS ? a.nchain : ICP_WGS), dim3(64 * a.nwaves), a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1159,7 +1168,7 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
 #ifdef ICP_LOOP_TIMING
         L.timing = ctx->icp_timing_dev;
 #endif
-        KLAUNCH(ctx, k_icp_loop, dim3(ICP_CHAINS), dim3(64 * ICP_MAX_WAVES), L);
+        KLAUNCH(ctx, k_icp_loop, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
         HIP_TRY(hipGetLastError());
         return 0;
     }
