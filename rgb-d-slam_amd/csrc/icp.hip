@@ -493,7 +493,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     }
 }
 
-// 5 waves per SIMD (<= 96 VGPRs): two 5-wave workgroups per CU, so all 512 chains are resident at once
+// 256 workgroups of 10 waves: one per CU, all 512 chains resident at once
 __global__ __launch_bounds__(64 * ICP_MAX_WAVES)
 void k_icp_iter(IcpIterArgs a) {
     ICP_SHARED_DECL(S);
@@ -1016,8 +1016,8 @@ extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
     if (cus <= 0 || (long)per_cu * cus < ICP_WGS) return RGBDSLAM_E_STATE;
     // The occupancy query packs waves freely over the four SIMDs of a CU; the dispatcher deals a workgroup's waves
-    // to the SIMDs starting from the first one (measured: at 144 registers = 3 waves per SIMD only ONE 5-wave
-    // workgroup was resident per CU and the loop starved), so SIMD 0 must have room for every workgroup's share.
+    // to the SIMDs starting from the first one (measured with 5-wave workgroups: at 144 registers = 3 waves per SIMD
+    // only ONE was resident per CU and the loop starved), so SIMD 0 must have room for every workgroup's share.
     hipFuncAttributes fa;
     HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_icp_loop));
     const int regs = ((fa.numRegs > 0 ? fa.numRegs : 512) + 7) & ~7;
