@@ -688,9 +688,16 @@ __device__ __forceinline__ float d_norm3(const float *v) { return __builtin_sqrt
 __device__ __forceinline__ constexpr int tri_idx(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); }
 #define SYM_A(S, i, j) ((S)[tri_idx((i) < (j) ? (i) : (j), (i) < (j) ? (j) : (i))])
 
+// value of v in lane src (src must be wave-uniform): v_readlane, a few cycles -- unlike __shfl, which goes through
+// the LDS crossbar (ds_bpermute) even for a constant lane
+__device__ __forceinline__ float lane_read(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
 // Partial-pivot LU determinant, one matrix ROW per lane (lanes 0..5), columns in registers: no
 // dynamically indexed private arrays (which would live in scratch memory) and no LDS round trips.
-// Pivot search and row exchange are the serial algorithm's, done with lane reads.
+// Pivot search and row exchange are the serial algorithm's, done with lane reads (columns left of the
+// pivot are never looked at again and are not exchanged).
 __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
     float a[6];
 #pragma unroll
@@ -704,16 +711,17 @@ __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         int p = c;
-        float best = __builtin_fabsf(__shfl(a[c], c));
+        float best = __builtin_fabsf(lane_read(a[c], c));
 #pragma unroll
         for (int r = c + 1; r < 6; r++) {
-            float v = __builtin_fabsf(__shfl(a[c], r));
+            float v = __builtin_fabsf(lane_read(a[c], r));
             if (v > best) { best = v; p = r; }
         }
+        p = __builtin_amdgcn_readfirstlane(p);
         float rowp[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            float vp = __shfl(a[k], p), vc = __shfl(a[k], c);
+        for (int k = c; k < 6; k++) {
+            float vp = lane_read(a[k], p), vc = lane_read(a[k], c);
             rowp[k] = vp;
             a[k] = (lane == c) ? vp : ((lane == p) ? vc : a[k]);   // exchange rows c and p (no-op when p == c)
         }
