@@ -254,6 +254,7 @@ void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__re
                    float *__restrict__ VMap_out, float *__restrict__ NMap_out, CalibV c, MergeClaimArgs ca, int n, int m) {
     if (!pb_tracked(pb)) return;
     __shared__ float sv[HALO_H][HALO_W][3];
+    __shared__ uint8_t smask[TILE_H][TILE_W];         // merged mask of the tile's own pixels, for the claim pass
     const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
     const int tid = threadIdx.y * TILE_W + threadIdx.x;
     for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
@@ -278,7 +279,7 @@ void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__re
                 const uint8_t mc = (newmask >= 0) ? (uint8_t)newmask : mk;
                 Mask_out[idx] = mc;
                 st3(VMap_out, idx, v.x, v.y, v.z);
-                if (ca.ParamTab) merge_claim(ca, pb->P_glob, v, mc, idx);
+                smask[r - 1][cc - 1] = mc;
             }
         }
         sv[r][cc][0] = v.x; sv[r][cc][1] = v.y; sv[r][cc][2] = v.z;
@@ -298,6 +299,9 @@ void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__re
         nr = normal_from_cross(p, dn, up, rt, lf, 1);
     }
     st3(NMap_out, (size_t)i * m + j, nr.x, nr.y, nr.z);
+    // The claim is a chain of dependent reads (label -> plane tables -> cell mask -> atomic): issued before the barrier
+    // it held every wave of the tile back; here only this wave waits for it.
+    if (ca.ParamTab) merge_claim(ca, pb->P_glob, p, smask[threadIdx.y][threadIdx.x], (size_t)i * m + j);
 }
 
 // =================================================================================================
