@@ -133,16 +133,20 @@ __global__ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const
                                unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
                                ReseedArgs rs, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (!pb_tracked(pb)) {
-        if (rs.fV && i < n && j < m) reseed_pixel(rs, c, i, j, n, m);
-        return;
-    }
-    if (i > n - 2 || j > m - 2) return;
+    // The tracked flag was written by the launch before this one: reading it is a memory round trip.  The quad's
+    // vertices are requested in the same round trip; the flag is only looked at before the first side effect.
+    const bool tracked = pb_tracked(pb);
+    const bool quad = !(i > n - 2 || j > m - 2);
     const float *P = pb->P_rel;
-    uint32_t q = (uint32_t)(i * (m - 1) + j), id[4];
+    uint32_t q = quad ? (uint32_t)(i * (m - 1) + j) : 0u, id[4];
     quad_vertex_ids(q, nullptr, m, id);
     F3 v0 = ld3(VMap, id[0]), v1 = ld3(VMap, id[1]), v2 = ld3(VMap, id[2]), v3 = ld3(VMap, id[3]);
     pin_loaded(v0); pin_loaded(v1); pin_loaded(v2); pin_loaded(v3);    // four loads in flight, then the warps
+    if (!tracked) {
+        if (rs.fV && i < n && j < m) reseed_pixel(rs, c, i, j, n, m);
+        return;
+    }
+    if (!quad) return;
     v0 = warp_vertex(P, v0); v1 = warp_vertex(P, v1); v2 = warp_vertex(P, v2); v3 = warp_vertex(P, v3);
     if (quad_trimmed(v0, v1, v2, v3, thresh)) return;
     F3 t0[3] = {v0, v1, v2}, t1[3] = {v0, v2, v3};
@@ -158,11 +162,13 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
                                   const uint8_t *__restrict__ Label_in, unsigned long long *__restrict__ zbuf,
                                   float *__restrict__ VMap_out, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
                                   uint8_t *__restrict__ Label_out, CalibV c, int n, int m) {
-    if (!pb_tracked(pb)) return;
+    const bool tracked = pb_tracked(pb);               // round trip shared with the z-buffer word (see k_predict_draw)
     int px = blockIdx.x * TILE_W + threadIdx.x, py = blockIdx.y * TILE_H + threadIdx.y;
     if (py >= n || px >= m) return;
     size_t p = (size_t)py * m + px;
     unsigned long long key = zbuf[p];
+    asm volatile("" : "+v"(key));
+    if (!tracked) return;
     float4 tex; tex.x = tex.y = tex.z = tex.w = 0.0f;
     if (key != ZBUF_EMPTY) {
         zbuf[p] = ZBUF_EMPTY;
@@ -201,24 +207,28 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
 __global__ void k_normal_segment(const rgbdslam_pose_block *__restrict__ pb, float *__restrict__ NMap,
                                  const float *__restrict__ VMap, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                  const float *__restrict__ Eq, float epsilon, float alpha, int n, int m) {
-    if (!pb_tracked(pb)) return;
+    const bool tracked = pb_tracked(pb);               // round trip shared with the pixel's own loads
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
-    F3 nl = normal_global(VMap, i, j, n, m, 1);
-    st3(NMap, idx, nl.x, nl.y, nl.z);
     uint8_t mine = in[idx];
+    F3 nl = normal_global(VMap, i, j, n, m, 1);
+    if (!tracked) return;
+    st3(NMap, idx, nl.x, nl.y, nl.z);
     if (mine == 0 && Eq) mine = segment_pixel(in, VMap, nl, pb->P_glob, Eq, epsilon, alpha, i, j, n, m);
     out[idx] = mine;
 }
 __global__ void k_segment_pass_pb(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ NMap,
                                   const float *__restrict__ VMap, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                   const float *__restrict__ Eq, float epsilon, float alpha, int n, int m) {
-    if (!pb_tracked(pb)) return;
+    const bool tracked = pb_tracked(pb);               // round trip shared with the pixel's own loads
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
-    uint8_t mine = in[idx];
+    int mine_w = in[idx];
+    asm volatile("" : "+v"(mine_w));                   // the load stays above the flag test
+    if (!tracked) return;
+    uint8_t mine = (uint8_t)mine_w;
     if (mine == 0) mine = segment_pixel(in, VMap, ld3(NMap, idx), pb->P_glob, Eq, epsilon, alpha, i, j, n, m);
     out[idx] = mine;
 }
