@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--icp-loop", type=int, default=1,
                     help="1 (default): persistent-loop ICP, one launch per frame (rgbdslam_set_icp_loop: this process owns the GPU "
                          "and uses one stream, which is how bench.py runs); 0: twelve k_icp_iter launches per frame")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: next frame's preprocessing and the Bump update on auxiliary streams (RG::overlap; measured slower)")
     ap.add_argument("--no-large-kernels", action="store_true", help="skip the config-3/config-4-size kernel rooflines")
     ap.add_argument("--profile-in-timed-region", action="store_true",
                     help="record the roofline events inside the timed region instead of in a second pass")
@@ -200,6 +202,8 @@ def main():
     host.slamhost_rg_ctx.restype = C.c_void_p
     ctx = C.c_void_p(host.slamhost_rg_ctx(rg._h))
     eq, centers = synth.plane_equations()
+    if args.overlap:
+        rg.set_overlap(True)
     if args.icp_loop:
         try:
             rg.set_icp_loop(True)
