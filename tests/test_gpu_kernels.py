@@ -600,3 +600,72 @@ def test_sharded_aligner_over_rccl_single_rank(pkg, orc, pair):
     finally:
         if started:
             dist.destroy_process_group()
+
+
+def test_icp_1080p_four_bands_and_persistent_loop(ctx, pkg, orc, synth):
+    """BASELINE configs[3] shape: a 1920x1080 pair.  (a) the full 27 sums of the first iteration at every level equal the
+    oracle's two-stage reduction; (b) four row bands (the 4-GPU split) give the oracle's banded sums; (c) the whole
+    Gauss-Newton loop through rgbdslam_track_frame -- 63 blocks per chain, 13 rounds -- leaves the same pose block with
+    one launch per iteration and with the persistent loop kernel, and that pose is the oracle's."""
+    import ctypes as C
+    n, m = 1080, 1920
+    calib = synth.calib_for(n, m)
+    d0, c0 = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    R1, t1 = synth.pair_offset_pose()
+    d1, c1 = synth.render(R1, t1, n, m, calib)
+    pr = {}
+    for k, (d, c) in enumerate([(d0, c0), (d1, c1)]):
+        v = orc.vertex_map_kinect(d, calib)
+        pr["v%d" % k] = v
+        pr["n%d" % k] = orc.compute_normal(v)
+        pr["rgb%d" % k] = orc.cpy_char3(c)
+    pr["rgbd0"] = orc.add_zbuff_off(d0, pr["rgb0"], calib)
+    _, pr["gx1"], pr["gy1"] = orc.intensity_sobel(pr["rgb1"])
+    ctx.set_calibration_matrix(calib)
+    gr, gc = orc.icp_grid(n, m, 1)
+    ctx.alloc_buffers(gr, gc)
+    g = {k: dev(pr[k]) for k in ("v0", "n0", "rgbd0", "v1", "n1", "rgb1", "gx1", "gy1")}
+    I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+    prm = pkg.icp_params()
+    sin20 = float(np.sin(np.deg2rad(20.0)))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib = ctx.lib
+    state = dev(np.concatenate([I, z, I, z]).astype(np.float32)); status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    assert lib.rgbdslam_align_begin(ctx._h, p(state), p(status)) == 0
+    gathered = torch.zeros(4, 27, device="cuda")
+    Rd, td, intr = dev(I), dev(z), dev(calib[:4])
+    for lvl in (2, 1, 0):
+        fact = 1 << lvl
+        lgr, lgc = orc.icp_grid(n, m, fact)
+        buf, _ = orc.icp_match(calib[:4], I, z, pr["v1"], pr["n1"], pr["rgb1"], pr["gx1"], pr["gy1"], pr["v0"], pr["n0"], pr["rgbd0"],
+                               0.05, sin20, fact)
+        A, b = ctx.estimate_system(Rd, td, g["v1"], g["n1"], g["rgb1"], g["gx1"], g["gy1"], g["v0"], g["n0"], g["rgbd0"], intr,
+                                   0.05, sin20, n, m, fact)
+        want = orc.icp_reduce(buf)
+        got = np.array([A[i * 6 + j] if j < 6 else b[i] for i in range(6) for j in range(i, 7)], np.float32)
+        same(got, want)
+        bounds = [lgr * k // 4 for k in range(5)]
+        b3 = buf.reshape(27, lgc, lgr)
+        for r in range(4):
+            lo, hi = bounds[r], bounds[r + 1]
+            assert lib.rgbdslam_align_band_system(ctx._h, C.byref(prm), p(g["v1"]), p(g["n1"]), p(g["rgb1"]), p(g["gx1"]),
+                                                  C.c_size_t(4 * m), p(g["gy1"]), C.c_size_t(4 * m), p(g["v0"]), p(g["n0"]),
+                                                  p(g["rgbd0"]), n, m, lvl, 0, lo, hi, C.c_void_p(gathered[r].data_ptr())) == 0
+            same(host(gathered[r]), orc.icp_reduce(np.ascontiguousarray(b3[:, :, lo:hi]).reshape(27, -1)))
+    out = []
+    for loop in (False, True):
+        ctx.set_icp_loop(loop)
+        pb = _pose_block(torch, I, z)
+        hist = torch.zeros(2, 16, device="cuda")
+        ctx.track_frame(prm, g["v1"], g["n1"], g["rgb1"], g["gx1"], g["gy1"], g["v0"], g["n0"], g["rgbd0"], n, m, pb, hist, 0)
+        ctx.synchronize()
+        if loop:
+            assert ctx.icp_loop_faults() == 0
+        out.append(host(pb).copy())
+    ctx.set_icp_loop(False)
+    same(out[1].view(np.int32), out[0].view(np.int32))
+    ok, R, t, tr = orc.align_gauss_newton(orc.icp_params(), calib[:4], pr["v1"], pr["n1"], pr["rgb1"], pr["v0"], pr["n0"], pr["rgbd0"],
+                                          I, z, I, z)
+    assert ok and out[1].view(np.int32)[24] == 1 and out[1].view(np.int32)[25] == len(tr)
+    same(out[1][:9], R)
+    same(out[1][9:12], t)
