@@ -669,3 +669,59 @@ def test_icp_1080p_four_bands_and_persistent_loop(ctx, pkg, orc, synth):
     assert ok and out[1].view(np.int32)[24] == 1 and out[1].view(np.int32)[25] == len(tr)
     same(out[1][:9], R)
     same(out[1][9:12], t)
+
+
+def test_decode_and_mesh_256_planes_full_size(ctx, orc):
+    """BASELINE configs[2] at its full size: 256 planes x 512x512 Bump cells, all byte values in the masks.
+    Size-independent properties: (a) eight plane ranges (the 8-GPU partition) reproduce the single launch bit for
+    bit and leave the planes outside their range untouched; (b) the per-plane entry point equals the batch;
+    (c) sampled planes equal the oracle; (d) the fused mesh launch equals decode + the oracle's normals and trim
+    on a sampled plane."""
+    planes, N = 256, 512
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bump = torch.randint(-32768, 32767, (planes, N, N, 3), dtype=torch.int16, device="cuda", generator=g)
+    rgbb = torch.randint(0, 256, (planes, N, N, 3), dtype=torch.uint8, device="cuda", generator=g)
+    mask = torch.randint(0, 256, (planes, N, N), dtype=torch.uint8, device="cuda", generator=g)
+    rng = np.random.default_rng(5)
+    prm = np.zeros((planes, 14), np.float32)
+    for k in range(planes):
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        e1 = np.cross(nrm, [0.3, -0.5, 0.8]); e1 /= np.linalg.norm(e1)
+        e2 = np.cross(nrm, e1)
+        prm[k] = [*nrm, rng.uniform(-3, 3), 500.0, 500.0, rng.uniform(-2, 0), rng.uniform(-2, 0), *e1, *e2]
+    param = dev(prm)
+    tab = lambda t: torch.tensor([t[k].data_ptr() for k in range(planes)], dtype=torch.int64, device="cuda")
+    itabs = [tab(x) for x in (bump, rgbb, mask, param)]
+
+    def decode(ranges):
+        outs = [torch.full((planes, N, N, ch), -7.0, device="cuda") for ch in (3, 4, 4)]
+        for lo, hi in ranges:
+            ctx.vertex_from_bump_batch(tab(outs[0]), tab(outs[1]), tab(outs[2]), *itabs, lo, hi, N, N)
+        ctx.synchronize()
+        return outs
+    full = decode([(0, planes)])
+    parts = decode([(planes * r // 8, planes * (r + 1) // 8) for r in range(8)])
+    for a, b in zip(full, parts):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    only = decode([(32, 64)])
+    assert float(only[0][:32].min()) == -7.0 and float(only[0][64:].max()) == -7.0
+    assert torch.equal(only[0][32:64].view(torch.int32), full[0][32:64].view(torch.int32))
+    for k in (0, 77, 255):
+        v = torch.empty(N, N, 3, device="cuda"); c = torch.empty(N, N, 4, device="cuda"); k4 = torch.empty(N, N, 4, device="cuda")
+        ctx.vertex_from_bump(v, c, k4, bump[k], rgbb[k], mask[k], param[k], N, N, 1)
+        rv, rc, rk = orc.vertex_from_bump(host(bump[k]).view(np.uint16), host(rgbb[k]), host(mask[k]), prm[k], 1)
+        for got, batch, want in ((v, full[0][k], rv), (c, full[1][k], rc), (k4, full[2][k], rk)):
+            same(host(got), want)
+            same(host(batch), want)
+    # mesh of the whole model in one launch vs the oracle on one plane
+    nout = torch.empty(planes, N, N, 3, device="cuda")
+    iout = torch.empty(planes, (N - 1) * (N - 1), 4, dtype=torch.int32, device="cuda")
+    outs = [torch.empty(planes, N, N, ch, device="cuda") for ch in (3, 4, 4)]
+    ctx.bump_mesh_batch(tab(outs[0]), tab(outs[1]), tab(outs[2]), tab(nout), tab(iout), *itabs, 0, planes, N, N, 0, 0.1, False, 0)
+    ctx.synchronize()
+    for a, b in zip(full, outs):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    k = 131
+    rv = host(full[0][k])
+    same(host(nout[k]), orc.compute_normal(rv, False))
+    same(host(iout[k]).view(np.uint32), orc.quad_trim(rv, host(mask[k]), 0, 0.1, 1, 0))
