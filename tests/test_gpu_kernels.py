@@ -725,3 +725,54 @@ def test_decode_and_mesh_256_planes_full_size(ctx, orc):
     rv = host(full[0][k])
     same(host(nout[k]), orc.compute_normal(rv, False))
     same(host(iout[k]).view(np.uint32), orc.quad_trim(rv, host(mask[k]), 0, 0.1, 1, 0))
+
+
+def test_update_many_planes_eight_way_partition(ctx, orc, pair, synth):
+    """Fusion into a model of 120 planes (labels over the whole uint8 range that is in use), two frames with
+    different confidences: eight plane ranges (the 8-GPU partition of configs[2]) == one launch == the oracle."""
+    n, m = 480, 640
+    nb, N_prim = 120, 256
+    rng = np.random.default_rng(17)
+    v = pair["v0"]
+    params = []
+    for k in range(nb):
+        # planes through random pixels of the frame, random in-plane axes: every plane receives observations
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        e1 = np.cross(nrm, [0.2, 0.9, -0.4]); e1 /= np.linalg.norm(e1)
+        e2 = np.cross(nrm, e1)
+        c = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(1, 3)])
+        scale = np.float32(2.0 / 0.004)
+        sh0 = np.float32(c @ e1 - N_prim * 0.004 / 2.0); sh1 = np.float32(c @ e2 - N_prim * 0.004 / 2.0)
+        params.append(np.array([*nrm, -(nrm @ c), scale, scale, sh0, sh1, *e1, *e2], np.float32))
+    label = rng.integers(0, nb + 1, (n, m)).astype(np.uint8)
+    I16 = pose16(np.eye(3), np.zeros(3))
+    frames = [rng.integers(0, 40, (n, m)).astype(np.uint8), rng.integers(0, 80, (n, m)).astype(np.uint8)]
+
+    def run(parts):
+        g_b = [torch.zeros(N_prim, N_prim, 3, dtype=torch.int16, device="cuda") for _ in range(nb)]
+        g_c = [torch.zeros(N_prim, N_prim, 3, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        g_m = [torch.zeros(N_prim, N_prim, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        g_k = [torch.zeros(N_prim, N_prim, dtype=torch.int64, device="cuda") for _ in range(nb)]
+        g_p = [dev(p) for p in params]
+        tabs = [_ptr_table(x) for x in (g_b, g_c, g_m, g_p, g_k)]
+        for stamp, mk in enumerate(frames, start=1):
+            for lo, hi in parts:
+                ctx.update(tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], stamp, dev(v), dev(pair["rgbd0"]), dev(mk), dev(label), I16,
+                           N_prim, N_prim, n, m, lo, hi)
+        return [host(x) for x in g_b + g_c + g_m]
+
+    full = run([(0, 2 ** 31 - 1)])
+    parts = run([(nb * r // 8, nb * (r + 1) // 8) for r in range(8)])
+    for a, b in zip(full, parts):
+        same(a, b)
+    bumps = [np.zeros((N_prim, N_prim, 3), np.uint16) for _ in range(nb)]
+    rgbs = [np.zeros((N_prim, N_prim, 3), np.uint8) for _ in range(nb)]
+    masks = [np.zeros((N_prim, N_prim), np.uint8) for _ in range(nb)]
+    claims = [np.zeros((N_prim, N_prim), np.uint64) for _ in range(nb)]
+    for stamp, mk in enumerate(frames, start=1):
+        orc.update(bumps, rgbs, masks, params, claims, stamp, v, pair["rgbd0"], mk, label, I16)
+    for k in range(nb):
+        same(full[k].view(np.uint16), bumps[k])
+        same(full[nb + k], rgbs[k])
+        same(full[2 * nb + k], masks[k])
+    assert sum(int((mk_ > 10).sum()) for mk_ in masks) > 1000
