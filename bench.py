@@ -50,7 +50,8 @@ PER_PX = {"k_frame_preprocess": 2 + 3 + 12 + 12 + 12 + 4 + 4,          # depth u
           "k_normal_segment": 12 + 12 + 1 + 1,                         # VMap -> NMap, Label in/out
           "k_segment_pass_pb": 12 + 12 + 1 + 1,
           "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12 + 1 + 1 + 8,   # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap; + claim pass: Label, cell mask, claim word
-          "k_update<false>": 12 + 1 + 1 + 8, "k_update<true>": 12 + 16 + 1 + 1 + 10}
+          "k_update<false>": 12 + 1 + 1 + 8, "k_update<true>": 12 + 16 + 1 + 1 + 10,
+          "k_update_apply_preprocess": (12 + 16 + 1 + 1 + 10) + (2 + 3 + 12 + 12 + 12 + 4 + 4)}   # apply pass of frame f + preprocess of f+1
 
 
 def hbm_bound_kernels(pkg, lib, synth, torch, device):
@@ -127,8 +128,12 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
     order = [1, 2, 3, 2, 1, 0, 1, 2]
     run_seq = lambda: rg.run_device_sequence([dd[i] for i in order], [bb[i] for i in order])
     run_seq()
-    for kernel in ("k_model_merge", "k_predict_resolve", "k_frame_preprocess", "k_predict_draw", "k_update<true>"):
-        tot, cnt = measure(ch, kernel, run_seq)
+    def run_single():                                # frame by frame: no next-frame hint, so the stand-alone kernels run
+        for i in order:
+            rg.run_device_sequence([dd[i]], [bb[i]])
+    for kernel, run in (("k_model_merge", run_seq), ("k_predict_resolve", run_seq), ("k_predict_draw", run_seq),
+                        ("k_update_apply_preprocess", run_seq), ("k_frame_preprocess", run_single), ("k_update<true>", run_single)):
+        tot, cnt = measure(ch, kernel, run)
         nbytes = PER_PX[kernel] * n * m
         gbs = nbytes * cnt / (tot * 1e-3) / 1e9
         out.append({"kernel": kernel, "workload": "fused frame pipeline at 1920x1080", "algorithmic_bytes_per_launch": nbytes,

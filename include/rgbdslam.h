@@ -227,6 +227,18 @@ int rgbdslam_update_tracked(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_b
                             uint64_t **ClaimTab, uint32_t stamp, const float *VMap, const float *RGBD,
                             const uint8_t *Mask, const uint8_t *Label, int N_prim, int M_prim, int n,
                             int m, int plane_lo, int plane_hi);
+/* rgbdslam_update_apply_tracked for frame f and rgbdslam_frame_preprocess for frame f+1 (same n x m) in ONE launch.
+ * The two are independent once frame f's merge has run -- nothing in flight reads frame f's maps any more, so the
+ * caller may pass the same frame buffers -- and both are latency-bound, so the preprocessing tiles run in the
+ * issue slots the update leaves idle.  For callers that know the next frame while they enqueue this one
+ * (a recorded sequence, a capture queue); Graph::Update (Graph.cpp:74-84) + OffLineFrame::LoadFrame (Frame.cpp:43-77). */
+int rgbdslam_update_apply_tracked_preprocess(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, uint16_t **BumpTab,
+                                             uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                             uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                                             const uint8_t *Label, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                             int plane_hi, const uint16_t *next_depth, size_t depth_pitch_bytes,
+                                             const uint8_t *next_bgr, size_t bgr_pitch_bytes, float *fVMap, float *fNMap,
+                                             float *fRGB, float *gx, size_t gx_pitch, float *gy, size_t gy_pitch);
 /* The same, gated on and posed by the frame's entry of the pose history ring (16 floats written by
  * rgbdslam_track_frame: poseR(9, column-major) poset(3) tracked ...).  Unlike the pose block, the entry is
  * never rewritten by the next frame, so this call may run on another stream concurrently with the next

@@ -379,3 +379,88 @@ __device__ __forceinline__ bool update_cell(const F3 &p, const float *__restrict
     o.cell = ii * M_prim + jj; o.sa = a - (float)ii; o.sb = b - (float)jj;
     return true;
 }
+
+#define HALO_W (TILE_W + 2)
+#define HALO_H (TILE_H + 2)
+#define HALO_N (HALO_W * HALO_H)
+
+// ---- OffLineFrame::LoadFrame (D1/Frame.cpp:43-77) + gpu_cpy + 2 x cv::gpu::Sobel (D1/RG.cpp:807-810) --
+// one 64x4 tile (bx, by); shared by k_frame_preprocess and by the launch that appends the next frame's
+// preprocessing to the Bump update (k_update_apply_preprocess)
+struct PreprocessArgs {
+    const uint16_t *depth; size_t dpitch;
+    const uint8_t *bgr; size_t bpitch;
+    float *VMap, *NMap, *RGB, *gx; size_t gx_pitch; float *gy; size_t gy_pitch;
+    CalibV c;
+    int n, m;
+};
+__device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, const int bx, const int by) {
+    const uint16_t *__restrict__ depth = a.depth; const size_t dpitch = a.dpitch;
+    const uint8_t *__restrict__ bgr = a.bgr; const size_t bpitch = a.bpitch;
+    float *__restrict__ VMap = a.VMap, *__restrict__ NMap = a.NMap, *__restrict__ RGB = a.RGB;
+    float *__restrict__ gx = a.gx, *__restrict__ gy = a.gy;
+    const size_t gx_pitch = a.gx_pitch, gy_pitch = a.gy_pitch;
+    const CalibV &c = a.c;
+    const int n = a.n, m = a.m;
+    __shared__ float sv[HALO_H][HALO_W][3];   // vertices of the tile + halo
+    __shared__ float si[HALO_H][HALO_W];      // intensities, halo by reflect-101
+    const int j0 = bx * TILE_W, i0 = by * TILE_H;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
+        int r = e / HALO_W, cc = e % HALO_W;
+        int ii = i0 + r - 1, jj = j0 + cc - 1;
+        bool in_img = ii >= 0 && ii < n && jj >= 0 && jj < m;
+        F3 v; v.x = v.y = v.z = 0.0f;
+        if (in_img) v = vertex_from_depth(((const uint16_t *)((const char *)depth + (size_t)(n - ii - 1) * dpitch))[jj], ii, jj, c);
+        sv[r][cc][0] = v.x; sv[r][cc][1] = v.y; sv[r][cc][2] = v.z;
+        float inten = 0.0f;
+        if (ii <= n && jj <= m) {   // one past the edge is still needed (reflected)
+            int si_ = reflect101(ii, n), sj = reflect101(jj, m);
+            const uint8_t *px = bgr + (size_t)(n - si_ - 1) * bpitch + 3 * (size_t)sj;
+            // (float)((double)x / 255.0) == x / 255.0f: double rounding is innocuous for division (53 >= 2*24+2)
+            float fr = (float)px[2] / 255.0f, fg = (float)px[1] / 255.0f, fb = (float)px[0] / 255.0f;   // Kernel.cu:749-751
+            inten = ((fb + fg) + fr) / 3.0f;                                                           // Kernel.cu:678
+            if (in_img && r >= 1 && r <= TILE_H && cc >= 1 && cc <= TILE_W) {
+                size_t idx = (size_t)ii * m + jj;
+                st3(RGB, idx, fr, fg, fb);
+                st3(VMap, idx, v.x, v.y, v.z);
+            }
+        }
+        si[r][cc] = inten;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const int r = threadIdx.y + 1, cc = threadIdx.x + 1;
+    size_t idx = (size_t)i * m + j;
+    // normals (Frame.cpp:71, inverse = true)
+    F3 nr; nr.x = nr.y = nr.z = 0.0f;
+    F3 p; p.x = sv[r][cc][0]; p.y = sv[r][cc][1]; p.z = sv[r][cc][2];
+    if (!(i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f)) {
+        F3 dn, up, rt, lf;
+        dn.x = sv[r + 1][cc][0]; dn.y = sv[r + 1][cc][1]; dn.z = sv[r + 1][cc][2];
+        up.x = sv[r - 1][cc][0]; up.y = sv[r - 1][cc][1]; up.z = sv[r - 1][cc][2];
+        rt.x = sv[r][cc + 1][0]; rt.y = sv[r][cc + 1][1]; rt.z = sv[r][cc + 1][2];
+        lf.x = sv[r][cc - 1][0]; lf.y = sv[r][cc - 1][1]; lf.z = sv[r][cc - 1][2];
+        nr = normal_from_cross(p, dn, up, rt, lf, 1);
+    }
+    st3(NMap, idx, nr.x, nr.y, nr.z);
+    // 3x3 Sobel, separable, the accumulation order of k_intensity_sobel
+    float rowd[3], rows[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = si[r - 1 + k][cc - 1], b = si[r - 1 + k][cc], d = si[r - 1 + k][cc + 1];
+        float s = 0.0f;
+        s = s + a * -1.0f; s = s + b * 0.0f; s = s + d * 1.0f;
+        rowd[k] = s;
+        s = 0.0f;
+        s = s + a * 1.0f; s = s + b * 2.0f; s = s + d * 1.0f;
+        rows[k] = s;
+    }
+    float s = 0.0f;
+    s = s + rowd[0] * 1.0f; s = s + rowd[1] * 2.0f; s = s + rowd[2] * 1.0f;
+    *(float *)((char *)gx + (size_t)i * gx_pitch + 4 * (size_t)j) = s;
+    s = 0.0f;
+    s = s + rows[0] * -1.0f; s = s + rows[1] * 0.0f; s = s + rows[2] * 1.0f;
+    *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
+}

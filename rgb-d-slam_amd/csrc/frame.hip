@@ -14,80 +14,11 @@
 // reads the 27 sums back 12 times per frame).
 #include "device_fns.hpp"
 
-#define HALO_W (TILE_W + 2)
-#define HALO_H (TILE_H + 2)
-#define HALO_N (HALO_W * HALO_H)
-
 __device__ __forceinline__ bool pb_tracked(const rgbdslam_pose_block *pb) { return pb->status[0] == 1; }
 
-// ---- OffLineFrame::LoadFrame (D1/Frame.cpp:43-77) + gpu_cpy + 2 x cv::gpu::Sobel (D1/RG.cpp:807-810) --
+// ---- OffLineFrame::LoadFrame + grey + 2 x Sobel: frame_preprocess_tile (device_fns.hpp) ---------------
 __global__ __launch_bounds__(TILE_W * TILE_H)
-void k_frame_preprocess(const uint16_t *__restrict__ depth, size_t dpitch, const uint8_t *__restrict__ bgr, size_t bpitch,
-                        float *__restrict__ VMap, float *__restrict__ NMap, float *__restrict__ RGB,
-                        float *__restrict__ gx, size_t gx_pitch, float *__restrict__ gy, size_t gy_pitch, CalibV c,
-                        int n, int m) {
-    __shared__ float sv[HALO_H][HALO_W][3];   // vertices of the tile + halo
-    __shared__ float si[HALO_H][HALO_W];      // intensities, halo by reflect-101
-    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
-    const int tid = threadIdx.y * TILE_W + threadIdx.x;
-    for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
-        int r = e / HALO_W, cc = e % HALO_W;
-        int ii = i0 + r - 1, jj = j0 + cc - 1;
-        bool in_img = ii >= 0 && ii < n && jj >= 0 && jj < m;
-        F3 v; v.x = v.y = v.z = 0.0f;
-        if (in_img) v = vertex_from_depth(((const uint16_t *)((const char *)depth + (size_t)(n - ii - 1) * dpitch))[jj], ii, jj, c);
-        sv[r][cc][0] = v.x; sv[r][cc][1] = v.y; sv[r][cc][2] = v.z;
-        float inten = 0.0f;
-        if (ii <= n && jj <= m) {   // one past the edge is still needed (reflected)
-            int si_ = reflect101(ii, n), sj = reflect101(jj, m);
-            const uint8_t *px = bgr + (size_t)(n - si_ - 1) * bpitch + 3 * (size_t)sj;
-            // (float)((double)x / 255.0) == x / 255.0f: double rounding is innocuous for division (53 >= 2*24+2)
-            float fr = (float)px[2] / 255.0f, fg = (float)px[1] / 255.0f, fb = (float)px[0] / 255.0f;   // Kernel.cu:749-751
-            inten = ((fb + fg) + fr) / 3.0f;                                                           // Kernel.cu:678
-            if (in_img && r >= 1 && r <= TILE_H && cc >= 1 && cc <= TILE_W) {
-                size_t idx = (size_t)ii * m + jj;
-                st3(RGB, idx, fr, fg, fb);
-                st3(VMap, idx, v.x, v.y, v.z);
-            }
-        }
-        si[r][cc] = inten;
-    }
-    __syncthreads();
-    const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
-    if (i >= n || j >= m) return;
-    const int r = threadIdx.y + 1, cc = threadIdx.x + 1;
-    size_t idx = (size_t)i * m + j;
-    // normals (Frame.cpp:71, inverse = true)
-    F3 nr; nr.x = nr.y = nr.z = 0.0f;
-    F3 p; p.x = sv[r][cc][0]; p.y = sv[r][cc][1]; p.z = sv[r][cc][2];
-    if (!(i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f)) {
-        F3 dn, up, rt, lf;
-        dn.x = sv[r + 1][cc][0]; dn.y = sv[r + 1][cc][1]; dn.z = sv[r + 1][cc][2];
-        up.x = sv[r - 1][cc][0]; up.y = sv[r - 1][cc][1]; up.z = sv[r - 1][cc][2];
-        rt.x = sv[r][cc + 1][0]; rt.y = sv[r][cc + 1][1]; rt.z = sv[r][cc + 1][2];
-        lf.x = sv[r][cc - 1][0]; lf.y = sv[r][cc - 1][1]; lf.z = sv[r][cc - 1][2];
-        nr = normal_from_cross(p, dn, up, rt, lf, 1);
-    }
-    st3(NMap, idx, nr.x, nr.y, nr.z);
-    // 3x3 Sobel, separable, the accumulation order of k_intensity_sobel
-    float rowd[3], rows[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float a = si[r - 1 + k][cc - 1], b = si[r - 1 + k][cc], d = si[r - 1 + k][cc + 1];
-        float s = 0.0f;
-        s = s + a * -1.0f; s = s + b * 0.0f; s = s + d * 1.0f;
-        rowd[k] = s;
-        s = 0.0f;
-        s = s + a * 1.0f; s = s + b * 2.0f; s = s + d * 1.0f;
-        rows[k] = s;
-    }
-    float s = 0.0f;
-    s = s + rowd[0] * 1.0f; s = s + rowd[1] * 2.0f; s = s + rowd[2] * 1.0f;
-    *(float *)((char *)gx + (size_t)i * gx_pitch + 4 * (size_t)j) = s;
-    s = 0.0f;
-    s = s + rows[0] * -1.0f; s = s + rows[1] * 0.0f; s = s + rows[2] * 1.0f;
-    *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
-}
+void k_frame_preprocess(PreprocessArgs a) { frame_preprocess_tile(a, blockIdx.x, blockIdx.y); }
 
 struct ReseedArgs {                                  // model := input frame (set A), used when the tracker reports a loss
     const float *fV, *fN, *fRGB;
@@ -324,8 +255,8 @@ extern "C" int rgbdslam_frame_preprocess(rgbdslam_ctx *ctx, const uint16_t *dept
     if (depth_pitch < 2 * (size_t)m || bgr_pitch < 3 * (size_t)m || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m)
         return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    KLAUNCH(ctx, k_frame_preprocess, grid2d(n, m), block2d(), depth, depth_pitch, bgr, bgr_pitch, VMap, NMap, RGB, gx, gx_pitch, gy,
-            gy_pitch, ctx->calib, n, m);
+    PreprocessArgs a = {depth, depth_pitch, bgr, bgr_pitch, VMap, NMap, RGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    KLAUNCH(ctx, k_frame_preprocess, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

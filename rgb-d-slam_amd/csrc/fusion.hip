@@ -6,13 +6,29 @@
 // A wavefront is 64 consecutive pixels of one image row and almost always sees ONE label: then the plane's table
 // entries and its 14 parameters are fetched once per wave through a wave-uniform address (scalar loads) instead of
 // once per lane, which takes two vector-memory round trips out of the chain.
+struct UpdateArgs {
+    uint16_t *const *BumpTab; uint8_t *const *RGBTab; uint8_t *const *MaskTab; float *const *ParamTab;
+    unsigned long long *const *ClaimTab;
+    uint32_t stamp;
+    const float *VMap, *RGBD; const uint8_t *Mask, *Label;
+    PoseV P;
+    const rgbdslam_pose_block *pb;
+    const float *hist;
+    int N_prim, M_prim, n, m, plane_lo, plane_hi;
+};
+// one 64x4 tile (bx, by) of UpdateKernel; APPLY = second pass of the winner rule
 template <bool APPLY>
-__global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *__restrict__ RGBTab,
-                         uint8_t *const *__restrict__ MaskTab, float *const *__restrict__ ParamTab,
-                         unsigned long long *const *__restrict__ ClaimTab, uint32_t stamp,
-                         const float *__restrict__ VMap, const float *__restrict__ RGBD, const uint8_t *__restrict__ Mask,
-                         const uint8_t *__restrict__ Label, PoseV P, const rgbdslam_pose_block *__restrict__ pb,
-                         const float *__restrict__ hist, int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi) {
+__device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, const int by) {
+    uint16_t *const *__restrict__ BumpTab = a.BumpTab; uint8_t *const *__restrict__ RGBTab = a.RGBTab;
+    uint8_t *const *__restrict__ MaskTab = a.MaskTab; float *const *__restrict__ ParamTab = a.ParamTab;
+    unsigned long long *const *__restrict__ ClaimTab = a.ClaimTab;
+    const uint32_t stamp = a.stamp;
+    const float *__restrict__ VMap = a.VMap, *__restrict__ RGBD = a.RGBD;
+    const uint8_t *__restrict__ Mask = a.Mask, *__restrict__ Label = a.Label;
+    PoseV P = a.P;
+    const rgbdslam_pose_block *__restrict__ pb = a.pb;
+    const float *__restrict__ hist = a.hist;
+    const int N_prim = a.N_prim, M_prim = a.M_prim, n = a.n, m = a.m, plane_lo = a.plane_lo, plane_hi = a.plane_hi;
     if (pb) {                                         // fused pipeline: pose from the device block, gated on it
         if (pb->status[0] != 1) return;
 #pragma unroll
@@ -25,7 +41,7 @@ __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *
         }
         P.v[12] = hist[9]; P.v[13] = hist[10]; P.v[14] = hist[11]; P.v[15] = 1.0f;
     }
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
     const bool in = i < n && j < m;
     const size_t idx = in ? (size_t)i * m + j : 0;
     int L = in ? (int)Label[idx] - 1 : -1;
@@ -80,6 +96,18 @@ __global__ void k_update(uint16_t *const *__restrict__ BumpTab, uint8_t *const *
         C[2] = (uint8_t)f2i_rn((float)((double)col.z * 255.0));
         *cellmask = mc;
     }
+}
+template <bool APPLY>
+__global__ void k_update(UpdateArgs a) { update_tile<APPLY>(a, blockIdx.x, blockIdx.y); }
+
+// Apply pass of Graph::Update for frame f AND OffLineFrame::LoadFrame of frame f+1 in one launch: the two are
+// independent (every reader of frame f's maps has finished before the apply pass starts), both are latency-bound, and
+// the preprocessing tiles fill the issue slots the update leaves idle.
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_update_apply_preprocess(UpdateArgs u, PreprocessArgs p, int gy_update) {
+    // tile rows alternate between the two jobs, so both kinds of workgroup are resident from the first wave on
+    if (blockIdx.y & 1) frame_preprocess_tile(p, blockIdx.x, (int)(blockIdx.y >> 1));
+    else update_tile<true>(u, blockIdx.x, (int)(blockIdx.y >> 1));
 }
 
 // ---- D1/Primitive.cu:31-93 VertexFromBumpKernel ----------------------------------------------------
@@ -166,10 +194,10 @@ static int launch_update(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, const
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;   // 23-bit pixel index in the claim key
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = pose ? pose[k] : 0.0f;
-    KLAUNCH(ctx, k_update<false>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab,
-            (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, hist, N_prim, M_prim, n, m, plane_lo, plane_hi);
-    KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab,
-            (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, hist, N_prim, M_prim, n, m, plane_lo, plane_hi);
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, hist,
+                    N_prim, M_prim, n, m, plane_lo, plane_hi};
+    KLAUNCH(ctx, k_update<false>, grid2d(n, m), block2d(), a);
+    KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -202,8 +230,37 @@ extern "C" int rgbdslam_update_apply_tracked(rgbdslam_ctx *ctx, const rgbdslam_p
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp,
-            VMap, RGBD, Mask, Label, P, pb, (const float *)nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi);
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, nullptr,
+                    N_prim, M_prim, n, m, plane_lo, plane_hi};
+    KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// rgbdslam_update_apply_tracked of frame f + rgbdslam_frame_preprocess of frame f+1 (same n x m) in one launch.
+extern "C" int rgbdslam_update_apply_tracked_preprocess(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, uint16_t **BumpTab,
+                                                        uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                                        uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                                                        const uint8_t *Label, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                                        int plane_hi, const uint16_t *next_depth, size_t depth_pitch,
+                                                        const uint8_t *next_bgr, size_t bgr_pitch, float *fVMap, float *fNMap,
+                                                        float *fRGB, float *gx, size_t gx_pitch, float *gy, size_t gy_pitch) {
+    if (!ctx || !pb || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !VMap || !RGBD || !Mask || !Label) return RGBDSLAM_E_ARG;
+    if (!next_depth || !next_bgr || !fVMap || !fNMap || !fRGB || !gx || !gy) return RGBDSLAM_E_ARG;
+    if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
+    if (depth_pitch < 2 * (size_t)m || bgr_pitch < 3 * (size_t)m || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m)
+        return RGBDSLAM_E_ARG;
+    if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    PoseV P;
+    for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
+    UpdateArgs u = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, nullptr,
+                    N_prim, M_prim, n, m, plane_lo, plane_hi};
+    PreprocessArgs p = {next_depth, depth_pitch, next_bgr, bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    dim3 grid = grid2d(n, m);
+    const int gy_update = (int)grid.y;
+    grid.y *= 2;
+    KLAUNCH(ctx, k_update_apply_preprocess, grid, block2d(), u, p, gy_update);
     HIP_TRY(hipGetLastError());
     return 0;
 }

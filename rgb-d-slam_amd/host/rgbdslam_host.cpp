@@ -255,10 +255,17 @@ void OffLineFrame::LoadFrame(const std::string &filename_depth, const std::strin
 }
 
 void OffLineFrame::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    const bool done = _pre.valid && !_load_stream && _pre.depth == depth_dev && _pre.depth_pitch == depth_pitch && _pre.bgr == bgr_dev &&
+                      _pre.bgr_pitch == bgr_pitch;
+    _pre.valid = false;
     begin_load();
     _depth_cur[_cur] = depth_dev;
     _depth_pitch[_cur] = depth_pitch;
-    preprocess(bgr_dev, bgr_pitch);
+    if (!done) preprocess(bgr_dev, bgr_pitch);
+}
+
+void OffLineFrame::MarkPreprocessed(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    _pre.depth = depth_dev; _pre.depth_pitch = depth_pitch; _pre.bgr = bgr_dev; _pre.bgr_pitch = bgr_pitch; _pre.valid = true;
 }
 
 void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
@@ -481,6 +488,16 @@ void Graph::ApplyTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb, c
                                         frame->_Mask_dev, frame->_Label_dev, t.N_prim, t.M_prim, frame->_n, frame->_m, t.plane_lo,
                                         t.plane_hi), "Update_cu (apply)");
 }
+void Graph::ApplyTrackedAndPreprocess(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t, OffLineFrame *next,
+                                      const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    const size_t gp = 4 * (size_t)frame->_m;
+    check(rgbdslam_update_apply_tracked_preprocess(_ctx, pb, t.Bump, t.RGB, t.Mask, t.Param, t.Claim, t.stamp, frame->getVMap(),
+                                                   frame->getRGB(), frame->_Mask_dev, frame->_Label_dev, t.N_prim, t.M_prim, frame->_n,
+                                                   frame->_m, t.plane_lo, t.plane_hi, depth_dev, depth_pitch, bgr_dev, bgr_pitch,
+                                                   next->getVMap(), next->getNMap(), next->getRGB(), next->getGx(), gp, next->getGy(), gp),
+          "Update_cu (apply) + next LoadFrame");
+    next->MarkPreprocessed(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
+}
 void Graph::UpdateFromHistory(PredictedFrame *frame, const float *history_entry_dev) {
     if (_nodes.size() == 0) return;
     if (!_tables_built) build_tables();
@@ -578,6 +595,11 @@ bool RG::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const ui
     _frame->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
     _count++;
     return true;
+}
+
+void RG::HintNextDeviceFrame(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    _next_hint.depth = depth_dev; _next_hint.depth_pitch = depth_pitch; _next_hint.bgr = bgr_dev; _next_hint.bgr_pitch = bgr_pitch;
+    _next_hint.valid = depth_dev && bgr_dev;
 }
 
 void RG::OpenDataset(const char *path, int Sizedata, bool real, bool RGBDRep) {
@@ -922,7 +944,12 @@ int RG::StepAsync() {
     _predicted_frame->MergeFused(_pb_dev, _frame, claim_in_merge ? &upd : nullptr);  // GP-demo.cpp:249 (+ claim pass of :260)
     if (ovl) _frame->release(main);                                                 // last reader of this frame's buffer set
     if (!ov) {
-        if (claim_in_merge) _graph->ApplyTracked(_predicted_frame, _pb_dev, upd);   // GP-demo.cpp:260
+        // GP-demo.cpp:260; when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides along:
+        // every reader of this frame's maps has been enqueued, so the same buffers take the next frame's
+        if (claim_in_merge && _next_hint.valid && !ovl && _frame->has_gradients())
+            _graph->ApplyTrackedAndPreprocess(_predicted_frame, _pb_dev, upd, _frame, _next_hint.depth, _next_hint.depth_pitch,
+                                              _next_hint.bgr, _next_hint.bgr_pitch);
+        else if (claim_in_merge) _graph->ApplyTracked(_predicted_frame, _pb_dev, upd);
     } else {
         if (_graph->_nodes.size() != 0) {
             // Graph::Update on its own stream, posed by this frame's history entry (the pose block is rewritten
@@ -937,6 +964,7 @@ int RG::StepAsync() {
             _update_pending = true;
         }
     }
+    _next_hint.valid = false;
     frames_done++;
     return first ? 2 : 1;
 }
@@ -1130,6 +1158,7 @@ int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, 
         long before = r->tracked_total;
         for (int k = 0; k < count; k++) {
             r->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
+            if (k + 1 < count) r->HintNextDeviceFrame(depth_dev[k + 1], depth_pitch, bgr_dev[k + 1], bgr_pitch);
             r->StepAsync();
         }
         r->Sync();                                             // the only host<->device sync of the sequence

@@ -104,6 +104,9 @@ public:
     void LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);
     void LoadFrame(const std::string &filename_depth, const std::string &filename_color);   // Frame.cpp:43-77 (image files)
     void LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    // The maps of the frame (depth_dev, bgr_dev) were already computed into this object's buffers by a launch the caller
+    // enqueued (rgbdslam_update_apply_tracked_preprocess): the LoadFrameDevice of exactly that frame launches nothing.
+    void MarkPreprocessed(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
     // fused pipeline: with gradients enabled, LoadFrame* runs rgbdslam_frame_preprocess (one kernel for
     // Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
     void EnableGradients(bool on);
@@ -132,6 +135,7 @@ private:
     hipEvent_t _ready[2] = {nullptr, nullptr}, _free[2] = {nullptr, nullptr};
     bool _free_recorded[2] = {false, false};
     bool _loaded_once = false;
+    struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false; } _pre;
 };
 
 // ---- D1/Frame.h:188-282 -----------------------------------------------------------------------
@@ -196,6 +200,9 @@ public:
     // then ApplyTracked
     bool begin_update(UpdateTables *t);
     void ApplyTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t);
+    // ApplyTracked + the preprocessing of the NEXT frame into `next`'s buffers, one launch
+    void ApplyTrackedAndPreprocess(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t, OffLineFrame *next,
+                                   const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
     void Clear();
     std::vector<Primitive *> _nodes;
     int _SizeVBUFF[2];
@@ -221,6 +228,9 @@ public:
     ~RG();
     bool LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host);   // RG.cpp:78-147 minus file I/O
     bool LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    // The device-resident frame that the NEXT LoadFrameDevice will name, if the caller knows it already (a recorded
+    // sequence): the fused pipeline then computes its maps in the launch of this frame's Bump update.
+    void HintNextDeviceFrame(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
     // file sources: the dataset part of the constructor (RG.h:145-156), RG::LoadFrame() as in
     // RG.cpp:78-147 (false once the sequence is exhausted), and the TUM trajectory of the frames processed so far
     void OpenDataset(const char *path, int Sizedata, bool real = false, bool RGBDRep = true);
@@ -274,6 +284,7 @@ public:
     int last_iterations = 0;
     int last_level_iterations = 0;   // packed per level, 8 bits each (device loop only)
     rgbdslam_ctx *ctx() { return _ctx; }
+    struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false; } _next_hint;
     std::vector<float> _Equations, _Centers;
     DevBuf<float> _Equations_dev;
 private:
