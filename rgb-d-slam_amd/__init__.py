@@ -348,6 +348,15 @@ class RG:
         _hchk(self.lib.slamhost_rg_load_frame_device(self._h, _ptr(depth_t), C.c_size_t(depth_pitch or 2 * self.m), _ptr(bgr_t),
                                                      C.c_size_t(bgr_pitch or 3 * self.m)), "load_frame_device")
 
+    def hint_next_device_frame(self, depth_t, bgr_t, depth_pitch=None, bgr_pitch=None):
+        """The device frame the NEXT load_frame_device will name: its maps are then computed in this frame's Bump-update
+        launch.  A hint that does not come true costs nothing but that work."""
+        _hchk(self.lib.slamhost_rg_hint_next_device_frame(self._h, _ptr(depth_t), C.c_size_t(depth_pitch or 2 * self.m), _ptr(bgr_t),
+                                                          C.c_size_t(bgr_pitch or 3 * self.m)), "hint_next_device_frame")
+
+    def step_async(self):
+        _hchk(self.lib.slamhost_rg_step_async(self._h), "step_async")
+
     def set_planes(self, equations, centers):
         eq = [float(x) for x in equations.reshape(-1)]
         ce = [float(x) for x in centers.reshape(-1)]

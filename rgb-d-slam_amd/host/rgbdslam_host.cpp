@@ -1140,6 +1140,12 @@ int slamhost_rg_step(void *rg, int *status) {
     return 0;
 }
 // fused pipeline: enqueue one display() pass without waiting for it (poses via slamhost_rg_history / _synchronize)
+// names the device frame the NEXT load_frame_device will pass (RG::HintNextDeviceFrame)
+int slamhost_rg_hint_next_device_frame(void *rg, const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    ((RG *)rg)->HintNextDeviceFrame(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
+    return 0;
+}
 int slamhost_rg_step_async(void *rg) {
     if (!rg) return RGBDSLAM_E_ARG;
     if (!((RG *)rg)->fused) return RGBDSLAM_E_STATE;

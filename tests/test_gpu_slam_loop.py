@@ -392,3 +392,36 @@ def test_loop_with_detected_planes(pkg, orc, synth, shape, min_size, fused):
         same(rg.buffer("Bump%d" % k), ref.buffer("Bump%d" % k), "Bump%d" % k)
     rg.close()
     ref.close()
+
+
+def test_next_frame_hint_true_false_and_absent(pkg, orc, synth):
+    """RG::HintNextDeviceFrame: the hinted frame's maps are computed in the Bump-update launch of the frame before it.
+    A hint that comes true, a hint that names ANOTHER frame than the one loaded next, and no hint at all must all give
+    the oracle's poses and model."""
+    n, m, N_prim = 120, 160, 256
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(7, n, m, calib, noise_sigma=0.001)
+    eq, centers = synth.plane_equations()
+    ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    ref.step(*seq[0]); rg.load_frame(*seq[0]); rg.step()
+    ref.set_planes(eq, centers); rg.set_planes(eq, centers)
+    dt = [torch.from_numpy(d).cuda() for d, _ in seq]
+    bt = [torch.from_numpy(c).cuda() for _, c in seq]
+    hints = {1: 2, 2: 5, 3: None, 4: 5, 5: 6}         # frame -> frame hinted while it is processed (2: wrong, 3: none)
+    for f in range(1, 7):
+        st = ref.step(*seq[f])
+        rg.load_frame_device(dt[f], bt[f])
+        h = hints.get(f)
+        if h is not None:
+            rg.hint_next_device_frame(dt[h], bt[h])
+        rg.step_async()
+    rg.synchronize()
+    hist = rg.history(1, 6)
+    R, t = ref.pose()
+    same(hist[5, :9], R, "poseR")
+    same(hist[5, 9:12], t, "poset")
+    for name in ("VMap", "NMap", "RGBD", "Mask", "Label", "Maskb0", "Bump1", "RGBb2"):
+        same(rg.buffer(name), ref.buffer(name), name)
+    rg.close()
+    ref.close()
