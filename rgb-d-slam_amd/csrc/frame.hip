@@ -177,15 +177,54 @@ struct MergeClaimArgs {
     uint32_t stamp;
     int N_prim, M_prim, plane_lo, plane_hi;
 };
-__device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const float *P_glob, F3 v, uint8_t mc, size_t idx) {
-    int L = (int)ca.Label[idx] - 1;
-    if (L < 0 || L < ca.plane_lo || L >= ca.plane_hi) return;
-    UpdCell u;
-    if (!update_cell(xf_point(P_glob, v), ca.ParamTab[L], ca.N_prim, ca.M_prim, u)) return;
-    const uint8_t mref = ca.MaskTab[L][u.cell];
-    const bool erode = (mc < 10 && mref != 1);                                // Primitive.cu:313
-    if (!erode && !(mc > mref)) return;                                       // Primitive.cu:341
-    atomicMax(ca.ClaimTab[L] + u.cell, claim_key(ca.stamp, !erode, erode ? (uint8_t)0 : mc, (uint32_t)idx));
+// `in`: this lane has a pixel (lanes outside the image take part in the wave-wide votes only)
+__device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const float *P_glob, F3 v, uint8_t mc, size_t idx, bool in) {
+    const int L = in ? (int)ca.Label[idx] - 1 : -1;
+    const bool valid = L >= 0 && L >= ca.plane_lo && L < ca.plane_hi;
+    const unsigned long long vmask = __ballot(valid);
+    if (!vmask) return;
+    // wave-uniform plane (the usual case: a 64-pixel row segment lies on one plane): table entries and the 14 plane
+    // parameters come through uniform addresses (scalar loads) instead of 16 dependent vector loads per lane
+    const int L0 = __builtin_amdgcn_readfirstlane(__shfl(L, (int)__builtin_ctzll(vmask)));
+    const bool one_plane = __ballot(valid && L != L0) == 0ull;
+    bool want = false;
+    unsigned long long key = 0ull, *slot = nullptr;
+    if (valid) {
+        UpdCell u;
+        const uint8_t *maskb;
+        unsigned long long *claimb;
+        const F3 p = xf_point(P_glob, v);
+        bool hit;
+        if (one_plane) {
+            const float *Q = ca.ParamTab[L0];
+            float q[14];
+#pragma unroll
+            for (int k = 0; k < 14; k++) q[k] = Q[k];
+            maskb = ca.MaskTab[L0]; claimb = ca.ClaimTab[L0];
+            hit = update_cell(p, q, ca.N_prim, ca.M_prim, u);
+        } else {
+            hit = update_cell(p, ca.ParamTab[L], ca.N_prim, ca.M_prim, u);
+            maskb = ca.MaskTab[L]; claimb = ca.ClaimTab[L];
+        }
+        if (hit) {
+            const uint8_t mref = maskb[u.cell];
+            const bool erode = (mc < 10 && mref != 1);                        // Primitive.cu:313
+            if (erode || mc > mref) {                                         // Primitive.cu:341
+                want = true;
+                key = claim_key(ca.stamp, !erode, erode ? (uint8_t)0 : mc, (uint32_t)idx);
+                slot = claimb + u.cell;
+            }
+        }
+    }
+    // Neighbouring pixels of a row often fall into the same cell (always, once the image is denser than the 4 mm
+    // cells).  On equal confidence the lower pixel index wins, i.e. the LEFT neighbour: a lane whose left neighbour
+    // claims the same cell with a key that is not smaller leaves the atomic to it; the maximum that reaches the
+    // cell is unchanged.
+    const int lane = threadIdx.x & 63;
+    const unsigned long long live = __ballot(want);
+    const unsigned long long slot_l = __shfl_up((unsigned long long)slot, 1), key_l = __shfl_up(key, 1);
+    const bool want_l = lane > 0 && ((live >> (lane - 1)) & 1ull);
+    if (want && !(want_l && slot_l == (unsigned long long)slot && key_l >= key)) atomicMax(slot, key);
 }
 
 __global__ __launch_bounds__(TILE_W * TILE_H)
@@ -227,22 +266,24 @@ void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__re
     }
     __syncthreads();
     const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
-    if (i >= n || j >= m) return;
+    const bool in = i < n && j < m;
     const int r = threadIdx.y + 1, cc = threadIdx.x + 1;
-    F3 nr; nr.x = nr.y = nr.z = 0.0f;
     F3 p; p.x = sv[r][cc][0]; p.y = sv[r][cc][1]; p.z = sv[r][cc][2];
-    if (!(i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f)) {
-        F3 dn, up, rt, lf;
-        dn.x = sv[r + 1][cc][0]; dn.y = sv[r + 1][cc][1]; dn.z = sv[r + 1][cc][2];
-        up.x = sv[r - 1][cc][0]; up.y = sv[r - 1][cc][1]; up.z = sv[r - 1][cc][2];
-        rt.x = sv[r][cc + 1][0]; rt.y = sv[r][cc + 1][1]; rt.z = sv[r][cc + 1][2];
-        lf.x = sv[r][cc - 1][0]; lf.y = sv[r][cc - 1][1]; lf.z = sv[r][cc - 1][2];
-        nr = normal_from_cross(p, dn, up, rt, lf, 1);
+    if (in) {
+        F3 nr; nr.x = nr.y = nr.z = 0.0f;
+        if (!(i < 1 || i > n - 2 || j < 1 || j > m - 2 || p.z == 0.0f)) {
+            F3 dn, up, rt, lf;
+            dn.x = sv[r + 1][cc][0]; dn.y = sv[r + 1][cc][1]; dn.z = sv[r + 1][cc][2];
+            up.x = sv[r - 1][cc][0]; up.y = sv[r - 1][cc][1]; up.z = sv[r - 1][cc][2];
+            rt.x = sv[r][cc + 1][0]; rt.y = sv[r][cc + 1][1]; rt.z = sv[r][cc + 1][2];
+            lf.x = sv[r][cc - 1][0]; lf.y = sv[r][cc - 1][1]; lf.z = sv[r][cc - 1][2];
+            nr = normal_from_cross(p, dn, up, rt, lf, 1);
+        }
+        st3(NMap_out, (size_t)i * m + j, nr.x, nr.y, nr.z);
     }
-    st3(NMap_out, (size_t)i * m + j, nr.x, nr.y, nr.z);
     // The claim is a chain of dependent reads (label -> plane tables -> cell mask -> atomic): issued before the barrier
     // it held every wave of the tile back; here only this wave waits for it.
-    if (ca.ParamTab) merge_claim(ca, pb->P_glob, p, smask[threadIdx.y][threadIdx.x], (size_t)i * m + j);
+    if (ca.ParamTab) merge_claim(ca, pb->P_glob, p, in ? smask[threadIdx.y][threadIdx.x] : (uint8_t)0, in ? (size_t)i * m + j : 0, in);
 }
 
 // =================================================================================================
