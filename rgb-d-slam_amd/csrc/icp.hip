@@ -14,7 +14,6 @@
                            // half as many sums to publish, to count and -- the expensive part -- to read back in the tail
 #define ICP_MAX_WAVES (ICP_CHAIN_WAVES * ICP_WG_CHAINS)
 #define ICP_WGS (ICP_CHAINS / ICP_WG_CHAINS)
-#define ICP_TAIL_TERMS ((27 + ICP_MAX_WAVES - 1) / ICP_MAX_WAVES)   // terms per wave in the tail
 #define ICP_TICKET_GROUP 16
 #define ICP_TICKET_WORDS (32 * (1 + 512 / ICP_TICKET_GROUP))
 #define ICP_CHAINS 512     // STRIDE (D1/cudaTypes.cuh:46): chains of ReduceKernel
@@ -199,7 +198,8 @@ struct IcpIterArgs {
     int grid_rows, grid_cols;                        // full 8x8-block grid (D1/ICP.cu:260-261)
     int br_lo, rows_local;                           // block-row band handled by this launch (row-sharded ICP)
     int nchain, nwaves;
-    float *chains;                                   // f32[27][512]
+    float *chains;                                   // 256 lines of 32 words: 27 sums + 4 sequence words (icp_chain_line)
+    unsigned int seq;                                // sequence word of this launch / step
     unsigned int *ticket;
     float *sums;                                     // f32[27] out
     int32_t *corr;                                   // optional debug map
@@ -264,6 +264,10 @@ struct IcpShared {
 // persistent loop: the model pixels a wave samples in its first two rounds are the same for every iteration of a
 // level (only the pose changes), so they stay in registers from one step to the next
 struct IcpModelCache { IcpModelPx r0, r1; int lvl; };
+// Line of the chain buffer that holds workgroup t's sums: the 32 workgroups c = 16j + 2v + h that wave v of the tail
+// folds (j = 0..15, h = 0..1) are stored back to back, in the order (j, h).
+__device__ __forceinline__ int icp_chain_line(int t) { return ((t >> 1) & 7) * 32 + ((t >> 4) << 1) + (t & 1); }
+
 // Every vector-memory store this wave has issued is acknowledged (agent-scope stores: at the device's coherence
 // point) before anything that follows is issued.  Part of the release ordering between the write-through stores
 // and the arrival counter / epoch that announces them.
@@ -412,18 +416,22 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         __syncthreads();
     }
     long long ts1 = a.timing ? wall_clock64() : 0;
-    // Publish the chain sums to the other XCDs without a full L2 write-back: agent-scope atomic
-    // stores are written through, icp_wait_stores() waits until they are acknowledged at that scope (an agent-scope
-    // release fence would add the write-back of the whole L2, a workgroup-scope one emits no wait at all here), and
-    // the last workgroup reads them back with agent-scope atomic loads (each XCD has its own L2).
     // offset 256 of reduce<512> (ICP.cu:35): chain t + chain t+256, added here instead of in the tail (a chain that does
     // not exist contributes the 0 the reference's memset leaves in its place)
     if (wave == ICP_CHAIN_WAVES && lane < 27) part[ICP_CHAIN_WAVES][lane] = acc;
     __syncthreads();
-    if (wave == 0 && lane < 27)
-        __hip_atomic_store(a.chains + lane * ICP_WGS + t, acc + part[ICP_CHAIN_WAVES][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    icp_wait_stores();
-    __syncthreads();
+    // Publish the 27 sums to the other XCDs without an L2 write-back and without waiting for an acknowledgement: ONE
+    // wave-wide agent-scope (write-through) store puts them into line icp_chain_line(t) of the chain buffer, laid out
+    // like the state line of the persistent loop -- term k in slot k + k/7, and a.seq (unique per launch / step) in the
+    // last slot of every 32-byte sector.  The reader checks those sequence words (below) instead of anyone waiting.
+    if (wave == 0) {
+        const float out = acc + part[ICP_CHAIN_WAVES][lane < 27 ? lane : 0];
+        const int k = lane - (lane >> 3);             // term held by slot `lane`
+        const float v = __shfl(out, k < 27 ? k : 0);
+        const unsigned int word = ((lane & 7) == 7) ? a.seq : __float_as_uint(v);
+        if (lane < 32)
+            __hip_atomic_store((unsigned int *)a.chains + 32 * icp_chain_line(t) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     long long ts2 = a.timing ? wall_clock64() : 0;
     // Two-level arrival counter (same-address device-scope atomics serialise at the memory side):
     // 16 workgroups share a group counter on its own 128-byte line, the last arrival of a group
@@ -443,38 +451,46 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     if (!last_flag) return;
     long long ts3 = a.timing ? wall_clock64() : 0;
 
-    // second stage, tree part (reduce<512>, ICP.cu:28-48): offsets 256,128,64 combine the 8 values a
-    // lane holds (t = lane + 64q), offsets 32..1 are lane shuffles.  Chains beyond nblk hold 0.
-    // Wave w owns terms w, w+W, w+2W...; all of its loads are issued before the first add so the
-    // tail costs one memory round trip, not one per term.
-    // The loads are unconditional (the buffer always holds 27 x 512 floats; out-of-range terms re-read term 26) and
-    // the unused values are replaced by 0 afterwards: predicated loads made the compiler wait for memory between them.
-    float x[ICP_TAIL_TERMS][4];
+    // second stage, tree part (reduce<512>, ICP.cu:28-48; offset 256 is already in the published sums).  The arrival
+    // counter only says that every workgroup's store has been ISSUED: a line is taken when the sequence word of each of
+    // its sectors is this step's, and the lines are re-read otherwise -- so nobody ever waits for a store
+    // acknowledgement.  Lane l reads slot l%32 of lines 2i + l/32; wave v (of eight) owns the 32 workgroups
+    // c = 16j + 2v + l/32, j = 0..15, stored back to back (icp_chain_line): offsets 128..16 are adds between the 16
+    // registers of a lane, offsets 8, 4, 2 go through LDS, offset 1 is one lane shuffle.  All loads are issued before the
+    // first check; workgroups beyond nwg count as 0.
+    if (wave < 8) {
+        const unsigned int *src = (const unsigned int *)a.chains + 32 * (32 * wave + (lane >> 5)) + (lane & 31);
+        const int c0 = 2 * wave + (lane >> 5);
+        const bool is_seq = (lane & 7) == 7;
+        float r[16];
+        for (;;) {                                    // a second pass only if some line's store had not landed yet
+            bool stale = false;
 #pragma unroll
-    for (int u = 0; u < ICP_TAIL_TERMS; u++) {
-        const int term = min(wave + ICP_MAX_WAVES * u, 26);
+            for (int j = 0; j < 16; j++)
+                r[j] = __uint_as_float(__hip_atomic_load(src + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++)
-            x[u][qd] = __hip_atomic_load(a.chains + term * ICP_WGS + lane + 64 * qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < 16; j++) {
+                const bool live = c0 + 16 * j < nwg;
+                stale |= live && __float_as_uint(r[j]) != a.seq;
+                r[j] = live ? r[j] : 0.0f;
+            }
+            if (__ballot(stale && is_seq) == 0ull) break;
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < off; j++) r[j] = r[j] + r[j + off];   // offsets 128, 64, 32, 16
+        tr[wave][lane] = r[0];
     }
-    if (nwg < ICP_WGS) {
-#pragma unroll
-        for (int u = 0; u < ICP_TAIL_TERMS; u++)
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) x[u][qd] = (lane + 64 * qd < nwg) ? x[u][qd] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < ICP_TAIL_TERMS; u++) {
-        int term = wave + ICP_MAX_WAVES * u;
-        x[u][0] = x[u][0] + x[u][2]; x[u][1] = x[u][1] + x[u][3];   // offset 128
-        float s = x[u][0] + x[u][1];                                 // offset 64
-        s = s + __shfl_down(s, 32);
-        s = s + __shfl_down(s, 16);
-        s = s + __shfl_down(s, 8);
-        s = s + __shfl_down(s, 4);
-        s = s + __shfl_down(s, 2);
-        s = s + __shfl_down(s, 1);
-        if (lane == 0 && term < 27) { fin[term] = s; a.sums[term] = s; }
+    __syncthreads();
+    if (wave == 0) {
+        const float q0 = tr[0][lane] + tr[4][lane], q1 = tr[1][lane] + tr[5][lane];   // offset 8
+        const float q2 = tr[2][lane] + tr[6][lane], q3 = tr[3][lane] + tr[7][lane];
+        const float p0 = q0 + q2, p1 = q1 + q3;                                       // offset 4
+        float q = p0 + p1;                                                            // offset 2
+        q = q + __shfl_down(q, 32);                                                   // offset 1 (lines 2i | 2i+1)
+        const int k = lane - (lane >> 3);
+        if (lane < 32 && (lane & 7) != 7 && k < 27) { fin[k] = q; a.sums[k] = q; }
     }
     long long ts4 = a.timing ? wall_clock64() : 0;
     if (tid <= (nwg + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) {   // ready for the next launch / step
@@ -577,7 +593,7 @@ void k_icp_loop(IcpLoopArgs L) {
             a.fact = 1 << a.lvl; a.grid_rows = grid_rows; a.grid_cols = grid_cols;
             a.br_lo = 0; a.rows_local = grid_rows; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
             a.chains = (float *)(L.block + ICP_OFF_CHAINS); a.ticket = (unsigned int *)(L.block + ICP_OFF_TICKET);
-            a.sums = (float *)(L.block + ICP_OFF_OUT); a.corr = nullptr;
+            a.sums = (float *)(L.block + ICP_OFF_OUT); a.corr = nullptr; a.seq = L.epoch_base + (unsigned int)s + 1u;
             a.state = (IcpState *)(L.block + ICP_OFF_STATE); a.pose_state = L.pb->pose_state;
             a.do_solve = 1;
             const int start = ICP_LV(start);
@@ -1085,6 +1101,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.nchain = (int)(nblk < ICP_CHAINS ? nblk : ICP_CHAINS);
     a.nwaves = ICP_MAX_WAVES;   // always full workgroups: the last one needs the waves for the 27-term tail
     a.chains = ctx->buf_dev; a.ticket = ctx->ticket_dev; a.sums = sums; a.corr = corr;
+    a.seq = ++ctx->icp_epoch_base;                        // one counter for both launch forms: a stale line never matches
     a.state = state; a.pose_state = pose_state; a.do_solve = do_solve; a.lvl = lvl; a.iter = iter; a.max_iter = max_iter;
     a.thr_alpha = thr_alpha; a.thr_tr = thr_tr; a.trace = trace;
     a.timing = ctx->icp_timing_dev;
@@ -1170,8 +1187,8 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
         L.n = n; L.m = m;
         for (int k = 0; k < 4; k++) L.intr4[k] = ctx->calib.v[k];
         L.nsteps = ns;
-        ctx->icp_epoch_base += 4096u;                          // > any step index: a stale word never releases a waiter
-        L.epoch_base = ctx->icp_epoch_base;
+        L.epoch_base = ctx->icp_epoch_base;                    // this launch owns base+1 .. base+4095 (epochs and sequence
+        ctx->icp_epoch_base += 4096u;                          // words): a stale word never releases a waiter or passes a check
         L.timeout_ticks = 5000000;                             // 50 ms of the 100 MHz wall clock
 #ifdef ICP_LOOP_TIMING
         L.timing = ctx->icp_timing_dev;
