@@ -36,11 +36,10 @@ struct rgbdslam_ctx {
     // ICP.cu:5-7 globals
     float *buf_dev;      // f32[27][512] chain sums (first reduction stage, ICP.cu:57-58)
     long long *icp_timing_dev;  // debug (rgbdslam_debug_icp_timing)
-    unsigned int *ticket_dev;   // last-workgroup-done counter of k_icp_iter
     float *outbuf_dev;   // f32[27]
     float *out_host;     // pinned f32[27]
     IcpState *icp_state; // device
-    char *icp_block;               // the one allocation behind buf_dev / ticket_dev / outbuf_dev / icp_state / icp_epoch_dev
+    char *icp_block;               // the one allocation behind buf_dev / outbuf_dev / icp_state / icp_epoch_dev
     unsigned int *icp_epoch_dev;   // k_icp_loop: [0] epoch word, [32] fault flag
     unsigned int icp_epoch_base;   // host-side monotonic base of the epoch word
     int icp_loop;                  // rgbdslam_set_icp_loop

@@ -19,7 +19,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->stream = (hipStream_t)stream;
     c->have_calib = false;
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
-    c->buf_dev = nullptr; c->ticket_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr; c->icp_epoch_dev = nullptr; c->icp_block = nullptr; c->icp_epoch_base = 0; c->icp_loop = 0;
+    c->buf_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr; c->icp_epoch_dev = nullptr; c->icp_block = nullptr; c->icp_epoch_base = 0; c->icp_loop = 0;
     c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_launches = 0; c->prof_in_group = false;
     *out = c;
     return 0;

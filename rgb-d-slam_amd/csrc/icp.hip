@@ -14,8 +14,6 @@
                            // half as many sums to publish, to count and -- the expensive part -- to read back in the tail
 #define ICP_MAX_WAVES (ICP_CHAIN_WAVES * ICP_WG_CHAINS)
 #define ICP_WGS (ICP_CHAINS / ICP_WG_CHAINS)
-#define ICP_TICKET_GROUP 16
-#define ICP_TICKET_WORDS (32 * (1 + 512 / ICP_TICKET_GROUP))
 #define ICP_CHAINS 512     // STRIDE (D1/cudaTypes.cuh:46): chains of ReduceKernel
 
 struct IcpRow { float g[7]; float c[7]; };
@@ -184,7 +182,7 @@ __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
 // ---- one Gauss-Newton iteration: match + both reduction stages (+ solve) in ONE launch -----------
 // Workgroup t owns "chain" t of ReduceKernel (D1/ICP.cu:57-58): the 8x8 blocks t, t+512, t+1024...
 // Its waves compute those blocks' 27 partial sums (one wave = one block), wave 0 adds them in chain
-// order, and the last workgroup to finish (ticket counter) folds the 512 chain sums per term in the
+// order, and the last workgroup of the grid (it waits until every line carries the launch's sequence words) folds the sums per term in the
 // pairing of reduce<512> and runs the 6x6 solve -- so one launch replaces the reference's
 // memset + MatchKernel + memset + ReduceKernel + D2H + host solve + H2D (D1/ICP.cu:254-286,
 // RG.cpp:851-901) with bit-identical sums.
@@ -200,7 +198,6 @@ struct IcpIterArgs {
     int nchain, nwaves;
     float *chains;                                   // 256 lines of 32 words: 27 sums + 4 sequence words (icp_chain_line)
     unsigned int seq;                                // sequence word of this launch / step
-    unsigned int *ticket;
     float *sums;                                     // f32[27] out
     int32_t *corr;                                   // optional debug map
     IcpState *state;                                 // optional: gates the launch / receives the solve
@@ -246,7 +243,6 @@ struct IcpShared {
     float (&solve_sh)[2];
     IcpState &sst;         // snapshot of the loop state (or of the caller's R, t, intr)
     float (&spose)[24];    // pose_state snapshot for the solve
-    int &last_flag;
 };
 #define ICP_SHARED_DECL(S)                                                       \
     __shared__ float part_[ICP_MAX_WAVES][27];                                   \
@@ -255,8 +251,7 @@ struct IcpShared {
     __shared__ float solve_sh_[2];                                               \
     __shared__ IcpState sst_;                                                    \
     __shared__ float spose_[24];                                                 \
-    __shared__ int last_flag_;                                                   \
-    IcpShared S = {part_, tr_, fin_, solve_sh_, sst_, spose_, last_flag_}
+    IcpShared S = {part_, tr_, fin_, solve_sh_, sst_, spose_}
 
 // One iteration as seen by workgroup blockIdx.x.  LOOP = called from the persistent k_icp_loop: the
 // state changes while the kernel runs, so it is read and written with agent-scope atomics (plain
@@ -296,7 +291,6 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     float (&solve_sh)[2] = S.solve_sh;
     IcpState &sst = S.sst;
     float (&spose)[24] = S.spose;
-    int &last_flag = S.last_flag;
     const int wave = tid >> 6, lane = tid & 63;
     const int nblk = a.rows_local * a.grid_cols;
     const int nwg = min(a.nchain, ICP_WGS);             // workgroups of this launch / step
@@ -433,22 +427,10 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             __hip_atomic_store((unsigned int *)a.chains + 32 * icp_chain_line(t) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     long long ts2 = a.timing ? wall_clock64() : 0;
-    // Two-level arrival counter (same-address device-scope atomics serialise at the memory side):
-    // 16 workgroups share a group counter on its own 128-byte line, the last arrival of a group
-    // bumps the top counter, the last arrival there owns the tail.
-    if (tid == 0) {
-        int g = t / ICP_TICKET_GROUP, ngroups = (nwg + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP;
-        unsigned int expect = (unsigned int)min(ICP_TICKET_GROUP, nwg - g * ICP_TICKET_GROUP);
-        unsigned int old = __hip_atomic_fetch_add(a.ticket + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int last = 0;
-        if (old == expect - 1u) {
-            old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (old == (unsigned int)ngroups - 1u);
-        }
-        last_flag = last;
-    }
-    __syncthreads();
-    if (!last_flag) return;
+    // No arrival counter: the LAST workgroup of the step (it is dispatched last and owns the shortest chains) is the tail.
+    // It re-reads the published lines until every one carries this step's sequence words -- one round trip after the
+    // last line has landed, instead of two dependent counter round trips before the first read.
+    if (t != nwg - 1) return;
     long long ts3 = a.timing ? wall_clock64() : 0;
 
     // second stage, tree part (reduce<512>, ICP.cu:28-48; offset 256 is already in the published sums).  The arrival
@@ -463,7 +445,8 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         const int c0 = 2 * wave + (lane >> 5);
         const bool is_seq = (lane & 7) == 7;
         float r[16];
-        for (;;) {                                    // a second pass only if some line's store had not landed yet
+        const long long t_poll = wall_clock64();
+        for (;;) {                                    // until every workgroup's line of this step has landed
             bool stale = false;
 #pragma unroll
             for (int j = 0; j < 16; j++)
@@ -475,6 +458,11 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
                 r[j] = live ? r[j] : 0.0f;
             }
             if (__ballot(stale && is_seq) == 0ull) break;
+            if (wall_clock64() - t_poll > 5000000) {  // 50 ms: a workgroup of this step never ran (the device is not ours):
+#pragma unroll
+                for (int j = 0; j < 16; j++) r[j] = __builtin_nanf("");   // the solve rejects the system, the frame counts as lost
+                break;
+            }
         }
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1)
@@ -493,11 +481,6 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         if (lane < 32 && (lane & 7) != 7 && k < 27) { fin[k] = q; a.sums[k] = q; }
     }
     long long ts4 = a.timing ? wall_clock64() : 0;
-    if (tid <= (nwg + ICP_TICKET_GROUP - 1) / ICP_TICKET_GROUP) {   // ready for the next launch / step
-        if (LOOP) __hip_atomic_store(a.ticket + 32 * tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else a.ticket[32 * tid] = 0u;
-    }
-    if (LOOP) icp_wait_stores();                       // the resets have landed before the epoch moves
     __syncthreads();
     if (a.do_solve) {
         IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
@@ -519,7 +502,7 @@ void k_icp_iter(IcpIterArgs a) {
 
 // ---- persistent coarse-to-fine loop: ALL iterations of a frame in one launch -----------------------
 // Workgroup t keeps chain t for every step.  Between two Gauss-Newton iterations the grid meets at an
-// epoch word: the tail workgroup of step s (the last one through the ticket counter) solves, commits
+// epoch word: the tail workgroup of step s (the last workgroup of the step's grid) solves, commits
 // the state and stores base + (next step that executes) -- the steps the multi-launch loop would have
 // started as no-ops (after convergence) are jumped over; >= nsteps ends the kernel.  The host only
 // launches this kernel when every workgroup fits on the device at once (rgbdslam_set_icp_loop), and a
@@ -531,8 +514,7 @@ struct IcpLoopLevel { int start, grid_rows, grid_cols, lvl, max_iter; };
 // loop, and what does not fit is spilled into vector registers and scratch memory.  The five ICP work
 // buffers are therefore one allocation with fixed offsets, and pose_state / status come from pb.
 #define ICP_OFF_CHAINS 0
-#define ICP_OFF_TICKET (27 * ICP_CHAINS * 4)
-#define ICP_OFF_OUT (ICP_OFF_TICKET + ICP_TICKET_WORDS * 4)
+#define ICP_OFF_OUT (ICP_WGS * 128)              // after the 256 chain lines
 #define ICP_OFF_STATE (ICP_OFF_OUT + 128)
 #define ICP_OFF_EPOCH (ICP_OFF_STATE + 128)      // fault flag of k_icp_loop at + 128
 #define ICP_OFF_PUB (ICP_OFF_EPOCH + 256)        // published loop state: one 128-byte line
@@ -592,7 +574,7 @@ void k_icp_loop(IcpLoopArgs L) {
             a.lvl = ICP_LV(lvl); a.max_iter = ICP_LV(max_iter);
             a.fact = 1 << a.lvl; a.grid_rows = grid_rows; a.grid_cols = grid_cols;
             a.br_lo = 0; a.rows_local = grid_rows; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
-            a.chains = (float *)(L.block + ICP_OFF_CHAINS); a.ticket = (unsigned int *)(L.block + ICP_OFF_TICKET);
+            a.chains = (float *)(L.block + ICP_OFF_CHAINS);
             a.sums = (float *)(L.block + ICP_OFF_OUT); a.corr = nullptr; a.seq = L.epoch_base + (unsigned int)s + 1u;
             a.state = (IcpState *)(L.block + ICP_OFF_STATE); a.pose_state = L.pb->pose_state;
             a.do_solve = 1;
@@ -1008,7 +990,6 @@ extern "C" int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid
         HIP_TRY(hipMalloc((void **)&ctx->icp_block, ICP_BLOCK_BYTES));
         HIP_TRY(hipMemset(ctx->icp_block, 0, ICP_BLOCK_BYTES));
         ctx->buf_dev = (float *)(ctx->icp_block + ICP_OFF_CHAINS);
-        ctx->ticket_dev = (unsigned int *)(ctx->icp_block + ICP_OFF_TICKET);
         ctx->outbuf_dev = (float *)(ctx->icp_block + ICP_OFF_OUT);
         ctx->icp_state = (IcpState *)(ctx->icp_block + ICP_OFF_STATE);
         ctx->icp_epoch_dev = (unsigned int *)(ctx->icp_block + ICP_OFF_EPOCH);
@@ -1023,7 +1004,7 @@ extern "C" int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid
 extern "C" int rgbdslam_free_buffers(rgbdslam_ctx *ctx) {
     if (!ctx) return RGBDSLAM_E_ARG;
     if (ctx->icp_block) { (void)hipFree(ctx->icp_block); ctx->icp_block = nullptr; }
-    ctx->buf_dev = nullptr; ctx->ticket_dev = nullptr; ctx->outbuf_dev = nullptr; ctx->icp_state = nullptr; ctx->icp_epoch_dev = nullptr;
+    ctx->buf_dev = nullptr; ctx->outbuf_dev = nullptr; ctx->icp_state = nullptr; ctx->icp_epoch_dev = nullptr;
     if (ctx->out_host) { (void)hipHostFree(ctx->out_host); ctx->out_host = nullptr; }
     return 0;
 }
@@ -1053,7 +1034,7 @@ extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
 }
 
 // faults[0] = number of k_icp_loop launches that gave up waiting since the last call (synchronises the
-// stream).  After a fault the arrival counters are reset and the mode is switched off.
+// stream).  After a fault the mode is switched off.
 extern "C" int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults) {
     if (!ctx || !faults) return RGBDSLAM_E_ARG;
     *faults = 0;
@@ -1064,7 +1045,6 @@ extern "C" int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (f) {
         HIP_TRY(hipMemsetAsync(ctx->icp_epoch_dev + 32, 0, sizeof(int), ctx->stream));
-        HIP_TRY(hipMemsetAsync(ctx->ticket_dev, 0, ICP_TICKET_WORDS * sizeof(unsigned int), ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->icp_loop = 0;
     }
@@ -1089,7 +1069,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     if (br_lo < 0) br_lo = 0;
     if (br_hi > gr) br_hi = gr;
     if (br_hi <= br_lo) return RGBDSLAM_E_ARG;
-    if (!ctx->buf_dev || !ctx->ticket_dev) return RGBDSLAM_E_STATE;
+    if (!ctx->buf_dev) return RGBDSLAM_E_STATE;
     IcpIterArgs a;
     a.intr = intr; a.R = R; a.t = t;
     a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
@@ -1100,7 +1080,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     long nblk = (long)a.rows_local * gc;
     a.nchain = (int)(nblk < ICP_CHAINS ? nblk : ICP_CHAINS);
     a.nwaves = ICP_MAX_WAVES;   // always full workgroups: the last one needs the waves for the 27-term tail
-    a.chains = ctx->buf_dev; a.ticket = ctx->ticket_dev; a.sums = sums; a.corr = corr;
+    a.chains = ctx->buf_dev; a.sums = sums; a.corr = corr;
     a.seq = ++ctx->icp_epoch_base;                        // one counter for both launch forms: a stale line never matches
     a.state = state; a.pose_state = pose_state; a.do_solve = do_solve; a.lvl = lvl; a.iter = iter; a.max_iter = max_iter;
     a.thr_alpha = thr_alpha; a.thr_tr = thr_tr; a.trace = trace;
