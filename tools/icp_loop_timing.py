@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Per-step phase stamps of the persistent ICP kernel (k_icp_loop).  Needs a library built with
 -DICP_LOOP_TIMING (cd rgb-d-slam_amd/csrc && touch icp.hip && make EXTRA=-DICP_LOOP_TIMING); the normal
-build carries no stamps.  Stamps per executed step, from the tail workgroup: start, after the match rounds,
-after the chain sums are published, after the ticket, after the reduce<512> tree, after solve + publication;
-slot 0 is workgroup 0's start of the step."""
+build carries no stamps.  Stamps per executed step, from the tail workgroup (the last workgroup of the step): start,
+after its match rounds, after its line of sums is stored, when it turns to the other workgroups' lines, after all
+lines have arrived and the reduce<512> tree is done, after solve + publication; slot 0 is workgroup 0's start."""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -40,7 +40,7 @@ for s in sorted(acc):
     gap = ""
     if prev_end is not None and len(prev_end) == len(a):
         gap = "hand-over %5.0f ns (previous publication -> this tail workgroup starts)" % ((a[:, 1] - prev_end).mean() * 10.0)
-    print("step %2d (%2d frames): rounds %6.0f | publish %5.0f | ticket %5.0f | tree %5.0f | solve+pub %5.0f | sum %6.0f ns   %s"
+    print("step %2d (%2d frames): rounds %6.0f | store %5.0f | - %5.0f | lines+tree %5.0f | solve+pub %5.0f | sum %6.0f ns   %s"
           % (s, len(a), *ph, ph.sum(), gap))
     prev_end = a[:, 6]
 rg.close()
