@@ -207,6 +207,17 @@ int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bloc
                          const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
                          size_t depth_pitch_bytes, const float *RGB, float *RGBD_out,
                          uint8_t *Mask_out, float *VMap_out, float *NMap_out, int n, int m);
+/* rgbdslam_model_normal_segment followed by rgbdslam_model_merge_claim, as three launches instead of four:
+ * [first label-growth pass + Merge] -> [second pass] -> [third pass + claim pass of Graph::Update].  Merge reads no labels
+ * and the growth passes read nothing Merge writes once they have a normal map of their own (NMap_seg != NMap_out), so
+ * the two share a launch (GP-demo.cpp:232-249,260; Frame.cpp:242,300-333,395; RG.cu:906-912).  Needs nbPlans > 0. */
+int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
+                                       const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap, const float *Equations_dev,
+                                       int nbPlans, float epsilon, float alpha, const float *RGBD_in, const uint8_t *Mask_in,
+                                       const uint16_t *depth, size_t depth_pitch_bytes, const float *RGB, float *RGBD_out,
+                                       uint8_t *Mask_out, float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
+                                       uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                       int plane_hi);
 /* PredictedFrame::Merge + the CLAIM pass of the Graph::Update that follows it in display() (GP-demo.cpp:249-260): the
  * claim of a pixel needs only its own merged vertex and mask, so it rides on the merge launch.  Follow with
  * rgbdslam_update_apply_tracked (same stamp, same tables) to finish the update. */

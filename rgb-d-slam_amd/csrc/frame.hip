@@ -134,34 +134,47 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
 }
 
 // ---- ComputeNormal of ReadFrame (Frame.cpp:242) + first SegmentKernel pass (RG.cu:252-320) ------------
-// Eq == nullptr (no planes yet): normals only, labels copied.
-__global__ void k_normal_segment(const rgbdslam_pose_block *__restrict__ pb, float *__restrict__ NMap,
-                                 const float *__restrict__ VMap, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                 const float *__restrict__ Eq, float epsilon, float alpha, int n, int m) {
-    const bool tracked = pb_tracked(pb);               // round trip shared with the pixel's own loads
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
-    size_t idx = (size_t)i * m + j;
-    uint8_t mine = in[idx];
-    F3 nl = normal_global(VMap, i, j, n, m, 1);
+// Eq == nullptr (no planes yet): normals only, labels copied.  Tile functions, so that launches can carry two jobs.
+struct SegArgs {
+    const rgbdslam_pose_block *pb;
+    float *NMap;                 // written by the first pass, read by the others
+    const float *VMap;
+    const uint8_t *in; uint8_t *out;
+    const float *Eq; float epsilon, alpha;
+    int n, m;
+};
+__device__ __forceinline__ void normal_segment_tile(const SegArgs &a, const int bx, const int by) {
+    const bool tracked = pb_tracked(a.pb);             // round trip shared with the pixel's own loads
+    int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
+    if (i >= a.n || j >= a.m) return;
+    size_t idx = (size_t)i * a.m + j;
+    uint8_t mine = a.in[idx];
+    F3 nl = normal_global(a.VMap, i, j, a.n, a.m, 1);
     if (!tracked) return;
-    st3(NMap, idx, nl.x, nl.y, nl.z);
-    if (mine == 0 && Eq) mine = segment_pixel(in, VMap, nl, pb->P_glob, Eq, epsilon, alpha, i, j, n, m);
-    out[idx] = mine;
+    st3(a.NMap, idx, nl.x, nl.y, nl.z);
+    if (mine == 0 && a.Eq) mine = segment_pixel(a.in, a.VMap, nl, a.pb->P_glob, a.Eq, a.epsilon, a.alpha, i, j, a.n, a.m);
+    a.out[idx] = mine;
 }
-__global__ void k_segment_pass_pb(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ NMap,
-                                  const float *__restrict__ VMap, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                  const float *__restrict__ Eq, float epsilon, float alpha, int n, int m) {
-    const bool tracked = pb_tracked(pb);               // round trip shared with the pixel's own loads
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
-    size_t idx = (size_t)i * m + j;
-    int mine_w = in[idx];
+// one later pass; returns the pixel's label (0 outside the image / when not tracked: `done` tells)
+__device__ __forceinline__ uint8_t segment_pass_tile(const SegArgs &a, const int bx, const int by, bool &done, size_t &idx_out) {
+    const bool tracked = pb_tracked(a.pb);             // round trip shared with the pixel's own loads
+    int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
+    done = false; idx_out = 0;
+    if (i >= a.n || j >= a.m) return 0;
+    size_t idx = (size_t)i * a.m + j;
+    int mine_w = a.in[idx];
     asm volatile("" : "+v"(mine_w));                   // the load stays above the flag test
-    if (!tracked) return;
+    if (!tracked) return 0;
     uint8_t mine = (uint8_t)mine_w;
-    if (mine == 0) mine = segment_pixel(in, VMap, ld3(NMap, idx), pb->P_glob, Eq, epsilon, alpha, i, j, n, m);
-    out[idx] = mine;
+    if (mine == 0) mine = segment_pixel(a.in, a.VMap, ld3(a.NMap, idx), a.pb->P_glob, a.Eq, a.epsilon, a.alpha, i, j, a.n, a.m);
+    a.out[idx] = mine;
+    done = true; idx_out = idx;
+    return mine;
+}
+__global__ void k_normal_segment(SegArgs a) { normal_segment_tile(a, blockIdx.x, blockIdx.y); }
+__global__ void k_segment_pass_pb(SegArgs a) {
+    bool done; size_t idx;
+    (void)segment_pass_tile(a, blockIdx.x, blockIdx.y, done, idx);
 }
 
 // ---- PredictedFrame::Merge (Frame.cpp:300-333): MergeDepthOff + VertexMapGL + ComputeNormal -----------
@@ -178,8 +191,9 @@ struct MergeClaimArgs {
     int N_prim, M_prim, plane_lo, plane_hi;
 };
 // `in`: this lane has a pixel (lanes outside the image take part in the wave-wide votes only)
-__device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const float *P_glob, F3 v, uint8_t mc, size_t idx, bool in) {
-    const int L = in ? (int)ca.Label[idx] - 1 : -1;
+// label = the pixel's plane label (0 = none)
+__device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const float *P_glob, F3 v, uint8_t mc, size_t idx, bool in, int label) {
+    const int L = in ? label - 1 : -1;
     const bool valid = L >= 0 && L >= ca.plane_lo && L < ca.plane_hi;
     const unsigned long long vmask = __ballot(valid);
     if (!vmask) return;
@@ -227,15 +241,27 @@ __device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const floa
     if (want && !(want_l && slot_l == (unsigned long long)slot && key_l >= key)) atomicMax(slot, key);
 }
 
-__global__ __launch_bounds__(TILE_W * TILE_H)
-void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ RGBD_in,
-                   const uint8_t *__restrict__ Mask_in, const uint16_t *__restrict__ depth, size_t dpitch,
-                   const float *__restrict__ RGB, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
-                   float *__restrict__ VMap_out, float *__restrict__ NMap_out, CalibV c, MergeClaimArgs ca, int n, int m) {
+struct MergeArgs {
+    const rgbdslam_pose_block *pb;
+    const float *RGBD_in; const uint8_t *Mask_in; const uint16_t *depth; size_t dpitch; const float *RGB;
+    float *RGBD_out; uint8_t *Mask_out; float *VMap_out, *NMap_out;
+    CalibV c;
+    MergeClaimArgs ca;
+    int n, m;
+};
+__device__ __forceinline__ void model_merge_tile(const MergeArgs &a, const int bx, const int by) {
+    const rgbdslam_pose_block *__restrict__ pb = a.pb;
+    const float *__restrict__ RGBD_in = a.RGBD_in; const uint8_t *__restrict__ Mask_in = a.Mask_in;
+    const uint16_t *__restrict__ depth = a.depth; const size_t dpitch = a.dpitch; const float *__restrict__ RGB = a.RGB;
+    float *__restrict__ RGBD_out = a.RGBD_out; uint8_t *__restrict__ Mask_out = a.Mask_out;
+    float *__restrict__ VMap_out = a.VMap_out, *__restrict__ NMap_out = a.NMap_out;
+    const CalibV &c = a.c;
+    const MergeClaimArgs &ca = a.ca;
+    const int n = a.n, m = a.m;
     if (!pb_tracked(pb)) return;
     __shared__ float sv[HALO_H][HALO_W][3];
     __shared__ uint8_t smask[TILE_H][TILE_W];         // merged mask of the tile's own pixels, for the claim pass
-    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    const int j0 = bx * TILE_W, i0 = by * TILE_H;
     const int tid = threadIdx.y * TILE_W + threadIdx.x;
     for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
         int r = e / HALO_W, cc = e % HALO_W;
@@ -283,7 +309,32 @@ void k_model_merge(const rgbdslam_pose_block *__restrict__ pb, const float *__re
     }
     // The claim is a chain of dependent reads (label -> plane tables -> cell mask -> atomic): issued before the barrier
     // it held every wave of the tile back; here only this wave waits for it.
-    if (ca.ParamTab) merge_claim(ca, pb->P_glob, p, in ? smask[threadIdx.y][threadIdx.x] : (uint8_t)0, in ? (size_t)i * m + j : 0, in);
+    if (ca.ParamTab) {
+        const size_t cidx = in ? (size_t)i * m + j : 0;
+        merge_claim(ca, pb->P_glob, p, in ? smask[threadIdx.y][threadIdx.x] : (uint8_t)0, cidx, in, in ? (int)ca.Label[cidx] : 0);
+    }
+}
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_model_merge(MergeArgs a) { model_merge_tile(a, blockIdx.x, blockIdx.y); }
+
+// PredictedFrame::Merge does not read labels and the label growth does not read anything Merge writes (given a normal
+// map of its own): the first growth pass and the merge share a launch, tile rows alternating between the two jobs.
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_normal_segment_merge(SegArgs sg, MergeArgs mg) {
+    if (blockIdx.y & 1) model_merge_tile(mg, blockIdx.x, (int)(blockIdx.y >> 1));
+    else normal_segment_tile(sg, blockIdx.x, (int)(blockIdx.y >> 1));
+}
+// last growth pass + the claim pass of Graph::Update for the same pixel (its merged vertex and mask were written by
+// the launch above)
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_segment_pass_claim(SegArgs sg, MergeClaimArgs ca, const float *__restrict__ VMap_merged, const uint8_t *__restrict__ Mask_merged) {
+    bool done; size_t idx;
+    const uint8_t mine = segment_pass_tile(sg, blockIdx.x, blockIdx.y, done, idx);
+    F3 v; v.x = v.y = v.z = 0.0f;
+    uint8_t mc = 0;
+    if (done) { v = ld3(VMap_merged, idx); mc = Mask_merged[idx]; }
+    if (!pb_tracked(sg.pb)) return;                  // wave-uniform
+    merge_claim(ca, sg.pb->P_glob, v, mc, idx, done, (int)mine);
 }
 
 // =================================================================================================
@@ -346,10 +397,13 @@ extern "C" int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_p
         return RGBDSLAM_E_ARG;
     if (nbPlans < 0 || nbPlans > 255 || (nbPlans > 0 && !Equations_dev)) return RGBDSLAM_E_LIMIT;
     const float *Eq = nbPlans > 0 ? Equations_dev : nullptr;
-    KLAUNCH(ctx, k_normal_segment, grid2d(n, m), block2d(), pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m);
+    SegArgs p1 = {pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m};
+    KLAUNCH(ctx, k_normal_segment, grid2d(n, m), block2d(), p1);
     if (Eq) {                                                    // passes 2 and 3 (D1/RG.cu:910-911)
-        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), pose_block_dev, NMap, VMap, Label_swap, Label, Eq, epsilon, alpha, n, m);
-        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m);
+        SegArgs p2 = p1, p3 = p1;
+        p2.in = Label_swap; p2.out = Label;
+        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p2);
+        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p3);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -363,8 +417,8 @@ extern "C" int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block
     if (RGBD_in == RGBD_out || Mask_in == Mask_out || n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
     MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
-    KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out,
-            VMap_out, NMap_out, ctx->calib, none, n, m);
+    MergeArgs a = {pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, ctx->calib, none, n, m};
+    KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -381,8 +435,43 @@ extern "C" int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;                   // 23-bit pixel index in the claim key
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
     MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, Label, stamp, N_prim, M_prim, plane_lo, plane_hi};
-    KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out,
-            VMap_out, NMap_out, ctx->calib, ca, n, m);
+    MergeArgs a = {pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, ctx->calib, ca, n, m};
+    KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// rgbdslam_model_normal_segment + rgbdslam_model_merge_claim as THREE launches instead of four: [first growth pass +
+// merge] -> [second pass] -> [third pass + claim].  NMap_seg = the normal map of the predicted frame that the growth
+// passes use; it must not be the merge's NMap_out.  Needs planes (nbPlans > 0).
+extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
+                                                  const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap,
+                                                  const float *Equations_dev, int nbPlans, float epsilon, float alpha,
+                                                  const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
+                                                  size_t depth_pitch, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
+                                                  float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
+                                                  uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m,
+                                                  int plane_lo, int plane_hi) {
+    if (!ctx || !pose_block_dev || !NMap_seg || !VMap_pred || !Label || !Label_swap || Label == Label_swap || !Equations_dev)
+        return RGBDSLAM_E_ARG;
+    if (!RGBD_in || !Mask_in || !depth || !RGB || !RGBD_out || !Mask_out || !VMap_out || !NMap_out) return RGBDSLAM_E_ARG;
+    if (!MaskTab || !ParamTab || !ClaimTab || stamp == 0 || N_prim <= 0 || M_prim <= 0) return RGBDSLAM_E_ARG;
+    if (RGBD_in == RGBD_out || Mask_in == Mask_out || NMap_seg == NMap_out || VMap_pred == VMap_out) return RGBDSLAM_E_ARG;
+    if (n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (nbPlans <= 0 || nbPlans > 255) return RGBDSLAM_E_LIMIT;
+    if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;                   // 23-bit pixel index in the claim key
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    SegArgs p1 = {pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, epsilon, alpha, n, m};
+    SegArgs p2 = p1, p3 = p1;
+    p2.in = Label_swap; p2.out = Label;
+    MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
+    MergeArgs mg = {pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, ctx->calib, none, n, m};
+    MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, nullptr, stamp, N_prim, M_prim, plane_lo, plane_hi};
+    dim3 grid2 = grid2d(n, m);
+    grid2.y *= 2;
+    KLAUNCH(ctx, k_normal_segment_merge, grid2, block2d(), p1, mg);
+    KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p2);
+    KLAUNCH(ctx, k_segment_pass_claim, grid2d(n, m), block2d(), p3, ca, (const float *)VMap_out, (const uint8_t *)Mask_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

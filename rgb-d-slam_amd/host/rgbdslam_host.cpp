@@ -377,6 +377,15 @@ void PredictedFrame::NormalSegmentFused(const rgbdslam_pose_block *pb, float *Eq
     check(rgbdslam_model_normal_segment(_ctx, pb, _NMap_dev.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans,
                                         0.1f, 0.9f, _n, _m), "model_normal_segment");
 }
+void PredictedFrame::SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans, OffLineFrame *frame,
+                                            const UpdateTables &claim) {
+    if (!_NMap_seg.p) _NMap_seg.alloc(3 * (size_t)_n * _m);   // normals of the predicted frame for the growth passes (Merge owns _NMap_dev)
+    check(rgbdslam_model_segment_merge_claim(_ctx, pb, _NMap_seg.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans, 0.1f,
+                                             0.9f, _RGB_alt.p, _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(),
+                                             _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p, claim.Mask, claim.Param, claim.Claim,
+                                             claim.stamp, claim.N_prim, claim.M_prim, _n, _m, claim.plane_lo, claim.plane_hi),
+          "model_segment_merge_claim");
+}
 void PredictedFrame::MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame, const UpdateTables *claim) {
     if (claim) {
         check(rgbdslam_model_merge_claim(_ctx, pb, _RGB_alt.p, _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(),
@@ -938,10 +947,15 @@ int RG::StepAsync() {
     if (ov && _update_pending) hip_check(hipStreamWaitEvent(main, _ev_updated, 0), "wait for the previous update");
     // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
     _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
-    _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);       // Frame.cpp:242 + 395
     UpdateTables upd;
     const bool claim_in_merge = !ov && _graph->begin_update(&upd);
-    _predicted_frame->MergeFused(_pb_dev, _frame, claim_in_merge ? &upd : nullptr);  // GP-demo.cpp:249 (+ claim pass of :260)
+    if (claim_in_merge && _nbPlan > 0) {
+        // Frame.cpp:242 + 395, GP-demo.cpp:249 and the claim pass of :260 in three launches
+        _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd);
+    } else {
+        _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);   // Frame.cpp:242 + 395
+        _predicted_frame->MergeFused(_pb_dev, _frame, claim_in_merge ? &upd : nullptr);  // GP-demo.cpp:249 (+ claim pass of :260)
+    }
     if (ovl) _frame->release(main);                                                 // last reader of this frame's buffer set
     if (!ov) {
         // GP-demo.cpp:260; when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides along:

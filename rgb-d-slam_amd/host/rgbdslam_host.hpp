@@ -155,6 +155,8 @@ public:
     void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *reseed_from);   // Transform..ProjectLabel gather
     void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
     // claim != null: the claim pass of the Graph::Update that follows rides on the merge launch
+    // NormalSegmentFused + MergeFused(claim) in three launches (rgbdslam_model_segment_merge_claim); needs planes
+    void SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans, OffLineFrame *frame, const UpdateTables &claim);
     void MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame, const struct UpdateTables *claim = nullptr);
     float *getVMap() { return _VMap_dev.p; }
     float *getNMap() { return _NMap_dev.p; }
@@ -166,6 +168,7 @@ private:
     rgbdslam_ctx *_ctx;
     DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev, _tex;
     DevBuf<float> _VMap_alt, _RGB_alt;   // model set B of the fused pipeline
+    DevBuf<float> _NMap_seg;             // normals of the predicted frame for the label growth (SegmentMergeClaimFused)
     DevBuf<uint8_t> _mask_a, _mask_b, _label_a, _label_b;
     DevBuf<uint32_t> _Index_dev;
     DevBuf<uint64_t> _zbuf;
