@@ -51,7 +51,9 @@ PER_PX = {"k_frame_preprocess": 2 + 3 + 12 + 12 + 12 + 4 + 4,          # depth u
           "k_segment_pass_pb": 12 + 12 + 1 + 1,
           "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12 + 1 + 1 + 8,   # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap; + claim pass: Label, cell mask, claim word
           "k_update<false>": 12 + 1 + 1 + 8, "k_update<true>": 12 + 16 + 1 + 1 + 10,
-          "k_update_apply_preprocess": (12 + 16 + 1 + 1 + 10) + (2 + 3 + 12 + 12 + 12 + 4 + 4)}   # apply pass of frame f + preprocess of f+1
+          "k_update_apply_preprocess": (12 + 16 + 1 + 1 + 10) + (2 + 3 + 12 + 12 + 12 + 4 + 4),   # apply pass of frame f + preprocess of f+1
+          "k_normal_segment_merge": (12 + 12 + 1 + 1) + (16 + 1 + 2 + 12 + 16 + 1 + 12 + 12),   # first growth pass + Merge
+          "k_segment_pass_claim": (12 + 12 + 1 + 1) + (12 + 1 + 1 + 8)}                         # last growth pass + claim pass
 
 
 def hbm_bound_kernels(pkg, lib, synth, torch, device):
@@ -131,7 +133,8 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
     def run_single():                                # frame by frame: no next-frame hint, so the stand-alone kernels run
         for i in order:
             rg.run_device_sequence([dd[i]], [bb[i]])
-    for kernel, run in (("k_model_merge", run_seq), ("k_predict_resolve", run_seq), ("k_predict_draw", run_seq),
+    for kernel, run in (("k_normal_segment_merge", run_seq), ("k_segment_pass_claim", run_seq), ("k_predict_resolve", run_seq),
+                        ("k_predict_draw", run_seq),
                         ("k_update_apply_preprocess", run_seq), ("k_frame_preprocess", run_single), ("k_update<true>", run_single)):
         tot, cnt = measure(ch, kernel, run)
         nbytes = PER_PX[kernel] * n * m
