@@ -160,20 +160,26 @@ __device__ __forceinline__ bool quad_trimmed(F3 a, F3 b, F3 c, F3 d, float thres
 
 struct RasTri { int X[3], Y[3]; double inv_d[3]; long long area; int order[3]; };
 
-__device__ __forceinline__ bool ras_setup(const F3 *vtx, const CalibV &c, RasTri &T) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        F3 v = vtx[k];
-        float dk = -v.z;
-        if (!(dk >= RASTER_MIN_DEPTH)) return false;
-        float u = (v.x / dk) * c.v[0] + c.v[2];
-        float w = (v.y / dk) * c.v[1] + c.v[3];
-        if (!(__builtin_fabsf(u) <= RASTER_GUARD) || !(__builtin_fabsf(w) <= RASTER_GUARD)) return false;
-        T.X[k] = f2i_rn(u * 256.0f);
-        T.Y[k] = f2i_rn(w * 256.0f);
-        T.inv_d[k] = 1.0 / (double)dk;
-        T.order[k] = k;
-    }
+// projection of one vertex: shared by the two triangles of a quad (k_predict_draw projects four vertices, not six)
+struct RasVert { int X, Y; double inv_d; bool ok; };
+__device__ __forceinline__ RasVert ras_project(F3 v, const CalibV &c) {
+    RasVert P; P.X = 0; P.Y = 0; P.inv_d = 0.0; P.ok = false;
+    float dk = -v.z;
+    if (!(dk >= RASTER_MIN_DEPTH)) return P;
+    float u = (v.x / dk) * c.v[0] + c.v[2];
+    float w = (v.y / dk) * c.v[1] + c.v[3];
+    if (!(__builtin_fabsf(u) <= RASTER_GUARD) || !(__builtin_fabsf(w) <= RASTER_GUARD)) return P;
+    P.X = f2i_rn(u * 256.0f);
+    P.Y = f2i_rn(w * 256.0f);
+    P.inv_d = 1.0 / (double)dk;
+    P.ok = true;
+    return P;
+}
+__device__ __forceinline__ bool ras_setup_projected(const RasVert &a, const RasVert &b, const RasVert &d, RasTri &T) {
+    if (!a.ok || !b.ok || !d.ok) return false;
+    T.X[0] = a.X; T.Y[0] = a.Y; T.inv_d[0] = a.inv_d; T.order[0] = 0;
+    T.X[1] = b.X; T.Y[1] = b.Y; T.inv_d[1] = b.inv_d; T.order[1] = 1;
+    T.X[2] = d.X; T.Y[2] = d.Y; T.inv_d[2] = d.inv_d; T.order[2] = 2;
     long long area = (long long)(T.X[1] - T.X[0]) * (T.Y[2] - T.Y[0]) - (long long)(T.Y[1] - T.Y[0]) * (T.X[2] - T.X[0]);
     if (area == 0) return false;
     if (area < 0) {
@@ -186,6 +192,9 @@ __device__ __forceinline__ bool ras_setup(const F3 *vtx, const CalibV &c, RasTri
     }
     T.area = area;
     return true;
+}
+__device__ __forceinline__ bool ras_setup(const F3 *vtx, const CalibV &c, RasTri &T) {
+    return ras_setup_projected(ras_project(vtx[0], c), ras_project(vtx[1], c), ras_project(vtx[2], c), T);
 }
 __device__ __forceinline__ long long ras_edge(int ax, int ay, int bx, int by, int px, int py) {
     return (long long)(bx - ax) * (py - ay) - (long long)(by - ay) * (px - ax);
@@ -205,11 +214,9 @@ __device__ __forceinline__ bool ras_cover(const RasTri &T, int px, int py, long 
     if (w[2] == 0 && !ras_topleft(T.X[0], T.Y[0], T.X[1], T.Y[1])) return false;
     return true;
 }
-// z-buffer pass for one triangle
-__device__ __forceinline__ void ras_draw(unsigned long long *__restrict__ zbuf, const F3 *vtx, uint32_t tri_id,
-                                         const CalibV &c, float znear, float zfar, int n, int m) {
-    RasTri T;
-    if (!ras_setup(vtx, c, T)) return;
+// z-buffer pass for one triangle (already set up)
+__device__ __forceinline__ void ras_draw_tri(unsigned long long *__restrict__ zbuf, const RasTri &T, uint32_t tri_id, float znear,
+                                             float zfar, int n, int m) {
     int xmn = min(T.X[0], min(T.X[1], T.X[2])), xmx = max(T.X[0], max(T.X[1], T.X[2]));
     int ymn = min(T.Y[0], min(T.Y[1], T.Y[2])), ymx = max(T.Y[0], max(T.Y[1], T.Y[2]));
     int x0 = max(0, (xmn + 255) >> 8), x1 = min(m - 1, xmx >> 8);
@@ -224,6 +231,12 @@ __device__ __forceinline__ void ras_draw(unsigned long long *__restrict__ zbuf, 
             unsigned long long key = ((unsigned long long)__float_as_uint(dpx) << 32) | (unsigned long long)(0xFFFFFFFFu - tri_id);
             atomicMin(&zbuf[(size_t)py * m + px], key);
         }
+}
+__device__ __forceinline__ void ras_draw(unsigned long long *__restrict__ zbuf, const F3 *vtx, uint32_t tri_id,
+                                         const CalibV &c, float znear, float zfar, int n, int m) {
+    RasTri T;
+    if (!ras_setup(vtx, c, T)) return;
+    ras_draw_tri(zbuf, T, tri_id, znear, zfar, n, m);
 }
 // resolve pass for the pixel (px, py) covered by triangle vtx with attributes att (r, g, b, depth/100)
 __device__ __forceinline__ float4 ras_shade(const F3 *vtx, const float4 *att, const CalibV &c, int px, int py) {
