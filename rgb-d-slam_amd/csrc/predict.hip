@@ -38,9 +38,11 @@ __global__ void k_raster_draw(unsigned long long *__restrict__ zbuf, const float
     quad_vertex_ids(q, index, m, id);
     F3 v0 = ld3(VMap, id[0]), v1 = ld3(VMap, id[1]), v2 = ld3(VMap, id[2]), v3 = ld3(VMap, id[3]);
     if (!index && quad_trimmed(v0, v1, v2, v3, thresh)) return;
-    F3 t0[3] = {v0, v1, v2}, t1[3] = {v0, v2, v3};
-    ras_draw(zbuf, t0, 2 * q, c, znear, zfar, n, m);
-    ras_draw(zbuf, t1, 2 * q + 1, c, znear, zfar, n, m);
+    // triangles (0,1,2) and (0,2,3): the four vertices are projected once
+    const RasVert p0 = ras_project(v0, c), p1 = ras_project(v1, c), p2 = ras_project(v2, c), p3 = ras_project(v3, c);
+    RasTri T;
+    if (ras_setup_projected(p0, p1, p2, T)) ras_draw_tri(zbuf, T, 2 * q, znear, zfar, n, m);
+    if (ras_setup_projected(p0, p2, p3, T)) ras_draw_tri(zbuf, T, 2 * q + 1, znear, zfar, n, m);
 }
 
 // pass 2: one thread per pixel; re-derives the winning triangle's weights, writes the texel and
