@@ -53,7 +53,7 @@ int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *launches);
 int rgbdslam_profile_event_overhead(rgbdslam_ctx *ctx, int pairs, double *mean_ms);
 /* Debug: int64[7] device words that receive wall_clock64 stamps (10 ns ticks) of the phases of the
  * last ICP iteration kernel: [0] first workgroup start, [1..6] the tail workgroup's start, rounds
- * done, chain sums published, arrival counted, tree done, solve done.  NULL switches it off. */
+ * done, its line of sums stored, (unused), all lines arrived + tree done, solve done.  NULL switches it off. */
 int rgbdslam_debug_icp_timing(rgbdslam_ctx *ctx, long long *timing7_dev);
 
 /* Kernel.cuh:7-8   void SetCalibrationMatrix(float *Calib_CPU); FreeCalibrationMatrix()

@@ -263,13 +263,6 @@ struct IcpModelCache { IcpModelPx r0, r1; int lvl; };
 // folds (j = 0..15, h = 0..1) are stored back to back, in the order (j, h).
 __device__ __forceinline__ int icp_chain_line(int t) { return ((t >> 1) & 7) * 32 + ((t >> 4) << 1) + (t & 1); }
 
-// Every vector-memory store this wave has issued is acknowledged (agent-scope stores: at the device's coherence
-// point) before anything that follows is issued.  Part of the release ordering between the write-through stores
-// and the arrival counter / epoch that announces them.
-__device__ __forceinline__ void icp_wait_stores() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // field-by-field copy: a struct assignment is one memcpy, and when the optimiser cannot split it the private copy
 // ends up in scratch -- or is "promoted" to LDS, which costs a read of the dispatch packet per launch
 __device__ __forceinline__ void icp_state_copy(IcpState *d, const IcpState *s) {
