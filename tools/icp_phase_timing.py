@@ -27,7 +27,7 @@ for fact in (4, 2, 1):
         ctx.estimate_system(Rd, td, maps[1][0], maps[1][1], maps[1][2], gx, gy, maps[0][0], maps[0][1], rgbd0, intr, 0.05, 0.342, n, m, fact)
         ts = timing.cpu().numpy().astype(np.int64)
         if rep >= 5: acc += np.diff(ts[[0, 1, 2, 3, 4, 5, 6]]) * 10.0 / 15
-    print("fact %d: tail-WG start after first WG %6.0f ns | rounds %6.0f | publish %6.0f | ticket %6.0f | tree %6.0f | solve/end %6.0f | total %6.0f ns"
+    print("fact %d: tail-WG start after first WG %6.0f ns | rounds %6.0f | line store %6.0f | - %6.0f | lines+tree %6.0f | solve/end %6.0f | total %6.0f ns"
           % (fact, *acc, acc.sum()))
 # with the solve: device-resident loop, stamps of the LAST launch (level 0, last iteration)
 state = dev(np.concatenate([I, z, I, z]).astype(np.float32)); status = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -37,5 +37,5 @@ for rep in range(20):
     ctx.align_gauss_newton(pkg.icp_params(), maps[1][0], maps[1][1], maps[1][2], gx, gy, maps[0][0], maps[0][1], rgbd0, n, m, state, status)
     ts = timing.cpu().numpy().astype(np.int64)
     if rep >= 5: acc += np.diff(ts) * 10.0 / 15
-print("loop, last launch (fact 1, with solve): start %6.0f | rounds %6.0f | publish %6.0f | ticket %6.0f | tree %6.0f | solve %6.0f | total %6.0f ns; iters %d"
+print("loop, last launch (fact 1, with solve): start %6.0f | rounds %6.0f | line store %6.0f | - %6.0f | lines+tree %6.0f | solve %6.0f | total %6.0f ns; iters %d"
       % (*acc, acc.sum(), int(status[1])))
