@@ -157,7 +157,8 @@ def test_find_blobs_serpentine(ctx, orc):
     assert (rs > 0).sum() == 8                           # eight diagonal pixels = eight blobs
 
 
-@pytest.mark.parametrize("shape,noise", [((480, 640), 0.0), ((480, 640), 0.0005), ((120, 160), 0.001), ((93, 131), 0.001)])
+@pytest.mark.parametrize("shape,noise", [((480, 640), 0.0), ((480, 640), 0.0005), ((120, 160), 0.001), ((93, 131), 0.001),
+                                         ((1080, 1920), 0.0005)])
 def test_detect_regions_fused(ctx, orc, synth, shape, noise):
     n, m = shape
     v, nm = scene(orc, synth, n, m, noise)
@@ -171,9 +172,10 @@ def test_detect_regions_fused(ctx, orc, synth, shape, noise):
     same(host(blob), rb)
     same(host(sizes), rs)
     if noise == 0.0:                                     # clean normals: the three walls of the corner scene come out whole
-        assert (rs > (5000 if n == 480 else 300)).sum() == 3
+        assert (rs > (5000 if n >= 480 else 300)).sum() == 3
     else:                                                # noisy normals shatter the walls into many blobs: a harder labelling case
-        assert (rs > 0).sum() > 3 and rs.max() > 1000
+        # (at 1080p the same noise on finer pixels leaves only small shards: many blobs, none large)
+        assert (rs > 0).sum() > 3 and rs.max() > (1000 if n < 1080 else 30)
     # a label image blocks its pixels (ThreshKernel): regions shrink accordingly
     label = np.zeros((n, m), np.uint8)
     label[: n // 2] = 1
