@@ -70,9 +70,27 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
         lib.rgbdslam_profile_kernel(ctx_h, None)
         return tot.value, cnt.value
 
+    # ---- what a plain streaming kernel reaches on THIS card (fractions against it, beside the nominal peak) ----
+    ctx = pkg.Context(device)
+    probe_bytes = 2 << 30
+    pa = torch.zeros(probe_bytes // 4, device="cuda"); pb_ = torch.ones(probe_bytes // 4, device="cuda")
+    stream = {}
+    for mode, name in ((0, "copy"), (1, "fill"), (2, "read")):
+        g_ = C.c_double()
+        rc = lib.rgbdslam_profile_hbm_stream(ctx._h, C.c_void_p(pa.data_ptr()), C.c_void_p(pb_.data_ptr()), C.c_size_t(probe_bytes),
+                                             mode, 10, C.byref(g_))
+        if rc != 0:
+            raise RuntimeError("rgbdslam_profile_hbm_stream: %d" % rc)
+        stream[name] = round(g_.value, 1)
+    del pa, pb_
+    torch.cuda.empty_cache()
+    # a kernel that reads r bytes and writes w bytes is priced against the time the probe needs for r read + w written
+    def measured_frac(gbs, rd, wr):
+        t_probe = rd / stream["read"] + wr / stream["fill"]
+        return round(gbs * t_probe / (rd + wr), 4)
+
     # ---- config 3: decode (VertexFromBump, 54 B per cell) of 256 planes x 512 x 512 ----
     planes, N = 256, 512
-    ctx = pkg.Context(device)
     g = torch.Generator(device="cuda").manual_seed(0)
     bump = torch.randint(0, 32767, (planes, N, N, 3), dtype=torch.int16, device="cuda", generator=g)
     rgbb = torch.randint(0, 255, (planes, N, N, 3), dtype=torch.uint8, device="cuda", generator=g)
@@ -93,7 +111,7 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
     gbs = nbytes * cnt / (tot * 1e-3) / 1e9
     out.append({"kernel": "k_vertex_from_bump_batch", "workload": "decode of 256 planes x 512x512 Bump cells, one launch",
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1),
-                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_stream": measured_frac(gbs, 10, 44)})
     # ---- the same model as a mesh (decode + normals + QuadTrim fused, 82 B per cell) ----
     nout = torch.empty(planes, N, N, 3, device="cuda")
     iout = torch.empty(planes, (N - 1) * (N - 1), 4, dtype=torch.int32, device="cuda")
@@ -109,7 +127,7 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
     gbs = nbytes * cnt / (tot * 1e-3) / 1e9
     out.append({"kernel": "k_bump_mesh", "workload": "mesh (decode + normals + quad trim) of 256 planes x 512x512, one launch",
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1),
-                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_stream": measured_frac(gbs, 10, 72)})
     del bump, rgbb, mask, vout, cout, kout, nout, iout, tabs, mtabs
     ctx.close()
     torch.cuda.empty_cache()
@@ -141,9 +159,11 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
         gbs = nbytes * cnt / (tot * 1e-3) / 1e9
         out.append({"kernel": kernel, "workload": "fused frame pipeline at 1920x1080", "algorithmic_bytes_per_launch": nbytes,
                     "avg_launch_us": round(tot / cnt * 1e3, 1), "achieved": round(gbs, 1), "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4)})
+                    "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_stream": round(gbs / stream["copy"], 4)})
     rg.close()
-    return out
+    return out, {"bytes": probe_bytes, "unit": "GB/s", **stream,
+                 "note": "k_hbm_stream, one 16-byte word per lane, workgroups in address order, 10 launches; copy counts read + written bytes"}
 
 
 def main():
@@ -311,12 +331,12 @@ def main():
                "sample": "%d frames of the same %dx%d sequence, oracle display() loop (scalar C, -O2, 1 thread)"
                          % (args.cpu_frames, m, n)}
 
-    large = None
+    large = probe = None
     if rank == 0 and world == 1 and not args.no_large_kernels:
         rg.close()
         del depth_dev, bgr_dev
         torch.cuda.empty_cache()
-        large = hbm_bound_kernels(pkg, lib, synth, torch, local)
+        large, probe = hbm_bound_kernels(pkg, lib, synth, torch, local)
 
     if rank == 0:
         out = {"metric": "ICP+fusion frames/sec at 640x480", "value": round(world * args.steps / dt, 2), "unit": "frames/s",
@@ -327,7 +347,7 @@ def main():
                                       % (m, n),
                           "sequences": world, "frames_resident_in_hbm": True,
                           "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame"},
-               "roofline": roofline, "cpu_baseline": cpu, "hbm_bound_kernels": large}
+               "roofline": roofline, "cpu_baseline": cpu, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
         print(json.dumps(out), flush=True)
     rg.close()
     if world > 1:

@@ -51,6 +51,12 @@ int rgbdslam_profile_kernel(rgbdslam_ctx *ctx, const char *kernel_name);
 int rgbdslam_profile_read(rgbdslam_ctx *ctx, double *total_ms, int *launches);
 /* mean elapsed time of `pairs` event pairs with nothing between their two records (the markers' own cost) */
 int rgbdslam_profile_event_overhead(rgbdslam_ctx *ctx, int pairs, double *mean_ms);
+/* Measurement probe, no counterpart in the reference: the rate a plain streaming kernel reaches on this card's HBM
+ * (SURVEY 8(d) asks for the per-kernel fractions against a measured figure as well as the nominal one).  `dst`, `src`:
+ * caller's device buffers of `bytes` bytes, 16-byte aligned, src holding finite floats.  mode 0 = copy (counts
+ * 2 x bytes), 1 = fill dst (bytes), 2 = read src (bytes).  One untimed launch, then `reps` timed ones; blocking. */
+int rgbdslam_profile_hbm_stream(rgbdslam_ctx *ctx, void *dst, const void *src, size_t bytes, int mode, int reps,
+                                double *gbytes_per_s);
 /* Debug: int64[7] device words that receive wall_clock64 stamps (10 ns ticks) of the phases of the
  * last ICP iteration kernel: [0] first workgroup start, [1..6] the tail workgroup's start, rounds
  * done, its line of sums stored, (unused), all lines arrived + tree done, solve done.  NULL switches it off. */

@@ -129,20 +129,19 @@ __global__ void k_vertex_from_bump(float *__restrict__ VMap, float *__restrict__
 // Whole-model decode in ONE launch (config 3: hundreds of planes): blockIdx.z = plane.  A wavefront
 // owns 256 consecutive cells; lane L decodes cells L, L+64, L+128, L+192 of them, so every store
 // instruction writes one contiguous run (768 B of VMap, 1 KB of RGBA / MaskOut) -- the outputs are
-// 82 % of the traffic.  x/255 comes from a 256-entry LDS table.  Needs lvl == 1.
+// 82 % of the traffic; the inputs come in through LDS (below).  x/255 comes from a 256-entry LDS table.  Needs lvl == 1.
 #define DEC_CELLS 4
+#define DEC_ST(v, p) __builtin_nontemporal_store(v, p)
 __global__ __launch_bounds__(256)
 void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *__restrict__ RGBATab,
                               float *const *__restrict__ MaskOutTab, const uint16_t *const *__restrict__ BumpTab,
                               const uint8_t *const *__restrict__ RGBTab, const uint8_t *const *__restrict__ MaskTab,
                               const float *const *__restrict__ ParamTab, int plane_lo, int n, int m) {
     __shared__ float lut[256];                                  // x / 255 for every byte: one division per thread
-    lut[threadIdx.x] = unorm8((uint8_t)threadIdx.x);
-    __syncthreads();
+    lut[threadIdx.x] = unorm8((uint8_t)threadIdx.x);          // (published by the barrier of either branch below)
     const int plane = plane_lo + blockIdx.z;
     const size_t cells = (size_t)n * m;
     const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * DEC_CELLS) + (threadIdx.x & 63);
-    if (base >= cells) return;
     const BumpParam P = load_param(ParamTab[plane]);
     auto unorm = [&](uint8_t x) { return lut[x]; };
     const uint16_t *__restrict__ Bump = BumpTab[plane];
@@ -153,16 +152,52 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
     float *__restrict__ MaskOut = MaskOutTab[plane];
     uint16_t b[DEC_CELLS][3];
     uint8_t c[DEC_CELLS][3], mk[DEC_CELLS];
+    // The 10 input bytes of a cell sit in three byte streams (6 + 3 + 1): read cell by cell they cost 7 narrow strided
+    // loads each.  A workgroup whose 1024 cells are all there and whose plane pointers are word-aligned fetches its
+    // 10 KB as 7 full-width coalesced loads per thread into LDS instead and picks the cells' bytes from there.
+    const size_t wg_cell0 = (size_t)blockIdx.x * (256 * DEC_CELLS);
+    const bool wide = DEC_CELLS == 4 && wg_cell0 + 256 * DEC_CELLS <= cells &&
+                      (((uintptr_t)Bump & 7) | ((uintptr_t)RGBb & 3) | ((uintptr_t)Maskb & 3)) == 0;
+    if (wide) {
+        __shared__ __align__(16) unsigned char stage[(6 + 3 + 1) * 256 * DEC_CELLS];
+        uint2 *sB = (uint2 *)stage;                                   // 6144 B = 768 x 8
+        uint32_t *sC = (uint32_t *)(stage + 6 * 256 * DEC_CELLS);     // 3072 B = 768 x 4
+        uint32_t *sM = (uint32_t *)(stage + 9 * 256 * DEC_CELLS);     // 1024 B = 256 x 4
+        const uint2 *gB = (const uint2 *)(Bump + 3 * wg_cell0);
+        const uint32_t *gC = (const uint32_t *)(RGBb + 3 * wg_cell0);
+        const uint32_t *gM = (const uint32_t *)(Maskb + wg_cell0);
+        const int t = threadIdx.x;
+        uint2 rb0 = gB[t], rb1 = gB[t + 256], rb2 = gB[t + 512];
+        uint32_t rc0 = gC[t], rc1 = gC[t + 256], rc2 = gC[t + 512], rm = gM[t];
+        sB[t] = rb0; sB[t + 256] = rb1; sB[t + 512] = rb2;
+        sC[t] = rc0; sC[t + 256] = rc1; sC[t + 512] = rc2;
+        sM[t] = rm;
+        __syncthreads();
+        const uint16_t *lB = (const uint16_t *)stage;
+        const uint8_t *lC = stage + 6 * 256 * DEC_CELLS, *lM = stage + 9 * 256 * DEC_CELLS;
 #pragma unroll
-    for (int k = 0; k < DEC_CELLS; k++) {                       // all loads first
-        size_t cell = base + 64 * k;
-        bool in = cell < cells;
+        for (int k = 0; k < DEC_CELLS; k++) {
+            const int lc = (int)(base + 64 * k - wg_cell0);
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            b[k][q] = in ? Bump[3 * cell + q] : (uint16_t)0;
-            c[k][q] = in ? RGBb[3 * cell + q] : (uint8_t)0;
+            for (int q = 0; q < 3; q++) {
+                b[k][q] = lB[3 * lc + q];
+                c[k][q] = lC[3 * lc + q];
+            }
+            mk[k] = lM[lc];
         }
-        mk[k] = in ? Maskb[cell] : (uint8_t)0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < DEC_CELLS; k++) {                   // all loads first
+            size_t cell = base + 64 * k;
+            bool in = cell < cells;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                b[k][q] = in ? Bump[3 * cell + q] : (uint16_t)0;
+                c[k][q] = in ? RGBb[3 * cell + q] : (uint8_t)0;
+            }
+            mk[k] = in ? Maskb[cell] : (uint8_t)0;
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < DEC_CELLS; k++) {
@@ -171,13 +206,13 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
         int i = (int)(cell / (size_t)m), j = (int)(cell % (size_t)m);
         BumpCell o = decode_cell(b[k][0], b[k][1], b[k][2], c[k][0], c[k][1], c[k][2], mk[k], P, (float)i, (float)j, unorm);
         // streaming outputs: written once, never re-read by this kernel
-        __builtin_nontemporal_store(o.v.x, VMap + 3 * cell);
-        __builtin_nontemporal_store(o.v.y, VMap + 3 * cell + 1);
-        __builtin_nontemporal_store(o.v.z, VMap + 3 * cell + 2);
+        DEC_ST(o.v.x, VMap + 3 * cell);
+        DEC_ST(o.v.y, VMap + 3 * cell + 1);
+        DEC_ST(o.v.z, VMap + 3 * cell + 2);
         typedef float vfloat4 __attribute__((ext_vector_type(4)));
         vfloat4 cv = {o.c.x, o.c.y, o.c.z, o.c.w}, kv = {o.k.x, o.k.y, o.k.z, o.k.w};
-        __builtin_nontemporal_store(cv, (vfloat4 *)(RGBA + 4 * cell));
-        __builtin_nontemporal_store(kv, (vfloat4 *)(MaskOut + 4 * cell));
+        DEC_ST(cv, (vfloat4 *)(RGBA + 4 * cell));
+        DEC_ST(kv, (vfloat4 *)(MaskOut + 4 * cell));
     }
 }
 

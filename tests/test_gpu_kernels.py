@@ -776,3 +776,25 @@ def test_update_many_planes_eight_way_partition(ctx, orc, pair, synth):
         same(full[nb + k], rgbs[k])
         same(full[2 * nb + k], masks[k])
     assert sum(int((mk_ > 10).sum()) for mk_ in masks) > 1000
+
+
+def test_hbm_stream_probe_moves_what_it_counts(ctx, pkg):
+    """The bandwidth probe behind bench.py's `hbm_stream_probe`: copy mode copies every 16-byte word (ragged tail of
+    < 16 bytes left alone), fill mode writes zeros, read mode writes nothing; bad arguments are refused."""
+    import ctypes as C
+    lib = pkg.load()
+    nbytes = (1 << 20) * 16 + 16 * 7                       # not a multiple of the grid size
+    src = torch.arange(nbytes // 4, dtype=torch.float32, device="cuda")
+    dst = torch.full((nbytes // 4,), -1.0, device="cuda")
+    rate = C.c_double()
+    call = lambda mode, nb=nbytes, reps=2: lib.rgbdslam_profile_hbm_stream(ctx._h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()),
+                                                                           C.c_size_t(nb), mode, reps, C.byref(rate))
+    assert call(2) == 0 and rate.value > 0
+    assert (dst == -1.0).all()                             # read mode leaves dst alone
+    assert call(0, nbytes - 20) == 0 and rate.value > 0    # 20 bytes short: the last whole 16-byte word is not touched
+    n_copied = (nbytes - 20) // 16 * 4
+    assert torch.equal(dst[:n_copied], src[:n_copied]) and (dst[n_copied:] == -1.0).all()
+    assert call(1) == 0 and (dst == 0.0).all()
+    assert call(3) != 0 and call(0, 8) != 0 and call(0, nbytes, 0) != 0
+    assert lib.rgbdslam_profile_hbm_stream(ctx._h, C.c_void_p(dst.data_ptr() + 4), C.c_void_p(src.data_ptr()), C.c_size_t(64), 0, 1,
+                                           C.byref(rate)) != 0   # misaligned
