@@ -798,3 +798,37 @@ def test_hbm_stream_probe_moves_what_it_counts(ctx, pkg):
     assert call(3) != 0 and call(0, 8) != 0 and call(0, nbytes, 0) != 0
     assert lib.rgbdslam_profile_hbm_stream(ctx._h, C.c_void_p(dst.data_ptr() + 4), C.c_void_p(src.data_ptr()), C.c_size_t(64), 0, 1,
                                            C.byref(rate)) != 0   # misaligned
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (45, 91), (64, 64), (33, 1024)])
+@pytest.mark.parametrize("skew", [(0, 0, 0), (1, 1, 3), (2, 2, 2), (3, 0, 1)])
+def test_decode_batch_ragged_sizes_and_unaligned_planes(ctx, orc, shape, skew):
+    """The whole-model decode fetches a workgroup's inputs with full-width loads when its 1024 cells are all there and
+    the plane's pointers are word-aligned, and cell by cell otherwise: both ways, and their mix inside one launch
+    (full workgroups followed by a ragged one; aligned and skewed planes side by side), must give the same bits.
+    skew = element offsets of the (Bump u16, RGB u8, Mask u8) planes inside their allocations."""
+    n, m = shape
+    rng = np.random.default_rng(n * 1000 + m + sum(skew))
+    param = np.array([0.3, -0.5, 0.81, -1.7, 500.0, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5], np.float32)
+    planes = []
+    for k, (sb, sc, sm) in enumerate(((0, 0, 0), skew)):
+        bump = rng.integers(0, 65536, (n, m, 3)).astype(np.uint16)
+        rgbb = rng.integers(0, 256, (n, m, 3)).astype(np.uint8)
+        mask = rng.integers(0, 60, (n, m)).astype(np.uint8)
+        store_b = torch.zeros(bump.size + 8, dtype=torch.int16, device="cuda")
+        store_c = torch.zeros(rgbb.size + 8, dtype=torch.uint8, device="cuda")
+        store_m = torch.zeros(mask.size + 8, dtype=torch.uint8, device="cuda")
+        gb = store_b[sb:sb + bump.size]; gb.copy_(dev(bump.view(np.int16).reshape(-1)))
+        gc = store_c[sc:sc + rgbb.size]; gc.copy_(dev(rgbb.reshape(-1)))
+        gm = store_m[sm:sm + mask.size]; gm.copy_(dev(mask.reshape(-1)))
+        assert gb.data_ptr() % 8 == (2 * sb) % 8 and gc.data_ptr() % 4 == sc % 4 and gm.data_ptr() % 4 == sm % 4
+        planes.append((bump, rgbb, mask, gb, gc, gm, (store_b, store_c, store_m)))
+    gp = dev(param)
+    outs = [[torch.full((n, m, ch), -7.0, device="cuda") for _ in planes] for ch in (3, 4, 4)]
+    ctx.vertex_from_bump_batch(_ptr_table(outs[0]), _ptr_table(outs[1]), _ptr_table(outs[2]), _ptr_table([p[3] for p in planes]),
+                               _ptr_table([p[4] for p in planes]), _ptr_table([p[5] for p in planes]), _ptr_table([gp, gp]), 0, 2, n, m)
+    for k, p in enumerate(planes):
+        rv, rc, rk = orc.vertex_from_bump(p[0], p[1], p[2], param, 1)
+        same(host(outs[0][k]), rv)
+        same(host(outs[1][k]), rc)
+        same(host(outs[2][k]), rk)
