@@ -316,7 +316,7 @@ def main():
                 "algorithmic_bytes_per_frame": bytes_per_frame, "icp_iterations_per_level": level_iters}
 
     # ---- CPU baseline: the oracle's display() loop on a bounded sample of the same sequence ----
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import oracle as orc
         ref = orc.Slam(n, m, calib)
@@ -330,6 +330,22 @@ def main():
         cpu = {"value": round(args.cpu_frames / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same %dx%d sequence, oracle display() loop (scalar C, -O2, 1 thread)"
                          % (args.cpu_frames, m, n)}
+        # the same sources with OpenMP over rows / blocks on the host cores this job may use
+        orc.use_openmp(True)
+        try:
+            ref = orc.Slam(n, m, calib)
+            ref.step(*pool[order[0]])
+            ref.set_planes(eq, centers)
+            nf = 3 * args.cpu_frames
+            c0 = time.perf_counter()
+            for i in order[1:1 + nf]:
+                ref.step(*pool[i])
+            cdt = time.perf_counter() - c0
+            ref.close()
+            cpu_all = {"value": round(nf / cdt, 3), "unit": "frames/s", "cores": orc.threads(), "kind": "port",
+                       "sample": "%d frames of the same sequence, the same oracle sources built with -fopenmp (bit-identical results)" % nf}
+        finally:
+            orc.use_openmp(False)
 
     large = probe = None
     if rank == 0 and world == 1 and not args.no_large_kernels:
@@ -347,7 +363,7 @@ def main():
                                       % (m, n),
                           "sequences": world, "frames_resident_in_hbm": True,
                           "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame"},
-               "roofline": roofline, "cpu_baseline": cpu, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
+               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
         print(json.dumps(out), flush=True)
     rg.close()
     if world > 1:

@@ -12,22 +12,40 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBS = {}
+_OMP = False
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def use_openmp(on):
+    """Switches every later call (and every Slam created later) between the default single-thread library and the
+    same sources compiled with -fopenmp (bit-identical results; bench.py's multi-core CPU baseline)."""
+    global _OMP, _LIB
+    _OMP = bool(on)
+    _LIB = None
+
+
+def threads():
+    return int(lib().orc_threads())
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "librgbdslam_oracle.so")
-        if not os.path.exists(path):
-            build()
-        _LIB = C.CDLL(path)
-        _LIB.orc_det6.restype = C.c_float
-        _LIB.orc_slam_create.restype = C.c_void_p
-        _LIB.orc_slam_buffer.restype = C.c_void_p
+        name = "librgbdslam_oracle_omp.so" if _OMP else "librgbdslam_oracle.so"
+        if name not in _LIBS:
+            path = os.path.join(_HERE, name)
+            if not os.path.exists(path):
+                build()
+            h = C.CDLL(path)
+            h.orc_det6.restype = C.c_float
+            h.orc_slam_create.restype = C.c_void_p
+            h.orc_slam_buffer.restype = C.c_void_p
+            _LIBS[name] = h
+        _LIB = _LIBS[name]
     return _LIB
 
 
@@ -293,12 +311,13 @@ class Slam:
     def __init__(self, n, m, calib, prm=None, max_planes=50, N_prim=1024, M_prim=1024, znear=0.5, zfar=10.0):
         self.n, self.m, self.N_prim, self.M_prim = n, m, N_prim, M_prim
         self.prm = prm or icp_params()
-        self._h = C.c_void_p(lib().orc_slam_create(n, m, _p(_f32(calib)), C.byref(self.prm), max_planes, N_prim,
+        self._lib = lib()                                     # the library (single-thread or OpenMP) current at creation
+        self._h = C.c_void_p(self._lib.orc_slam_create(n, m, _p(_f32(calib)), C.byref(self.prm), max_planes, N_prim,
                                                    M_prim, C.c_float(znear), C.c_float(zfar)))
 
     def close(self):
         if self._h:
-            lib().orc_slam_destroy(self._h)
+            self._lib.orc_slam_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -308,27 +327,27 @@ class Slam:
         """RG::Finish first branch: DetectPrimitives + CreatePrimitives -> (equations [k,10], centers [k,3])."""
         eq = np.zeros((max_planes, 10), np.float32)
         ce = np.zeros((max_planes, 3), np.float32)
-        lib().orc_slam_detect_planes.restype = C.c_int
-        nb = lib().orc_slam_detect_planes(self._h, int(min_size), int(min_normals), _p(eq), _p(ce))
+        self._lib.orc_slam_detect_planes.restype = C.c_int
+        nb = self._lib.orc_slam_detect_planes(self._h, int(min_size), int(min_normals), _p(eq), _p(ce))
         return eq[:nb], ce[:nb]
 
     def set_planes(self, equations, centers):
         eq = _f32(equations)
-        lib().orc_slam_set_planes(self._h, _p(eq), _p(_f32(centers)), eq.size // 10)
+        self._lib.orc_slam_set_planes(self._h, _p(eq), _p(_f32(centers)), eq.size // 10)
 
     def step(self, depth, bgr):
-        return lib().orc_slam_step(self._h, _p(np.ascontiguousarray(depth, np.uint16)),
+        return self._lib.orc_slam_step(self._h, _p(np.ascontiguousarray(depth, np.uint16)),
                                    _p(np.ascontiguousarray(bgr, np.uint8)))
 
     def pose(self):
         R = np.empty(9, np.float32)
         t = np.empty(3, np.float32)
-        lib().orc_slam_get_pose(self._h, _p(R), _p(t))
+        self._lib.orc_slam_get_pose(self._h, _p(R), _p(t))
         return R, t
 
     def buffer(self, name):
         nb = C.c_size_t()
-        ptr = lib().orc_slam_buffer(self._h, name.encode(), C.byref(nb))
+        ptr = self._lib.orc_slam_buffer(self._h, name.encode(), C.byref(nb))
         if not ptr:
             raise KeyError(name)
         raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nb.value,)).copy()

@@ -173,4 +173,7 @@ int orc_fit_planes(const int32_t *blob, const int32_t *sizes, const float *VMap,
                    uint8_t *Label, float *equations, float *centers, int n, int m, int min_size, int min_normals,
                    int max_planes);
 
+/* threads the row loops run on: 1 in the default build, omp_get_max_threads() in librgbdslam_oracle_omp.so */
+int orc_threads(void);
+
 #endif
