@@ -158,8 +158,12 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
     const size_t wg_cell0 = (size_t)blockIdx.x * (256 * DEC_CELLS);
     const bool wide = DEC_CELLS == 4 && wg_cell0 + 256 * DEC_CELLS <= cells &&
                       (((uintptr_t)Bump & 7) | ((uintptr_t)RGBb & 3) | ((uintptr_t)Maskb & 3)) == 0;
+    // staging area: the workgroup's 10 KB of inputs first, then (once every thread holds its bytes) 3 KB per wave in
+    // which the wave's 256 vertices are laid out as they are in memory, so that they leave as three full 16-byte-per-lane
+    // stores instead of twelve 4-byte ones at a 12-byte stride
+    __shared__ __align__(16) unsigned char stage[12 * 256 * DEC_CELLS];
+    float *vt = nullptr;
     if (wide) {
-        __shared__ __align__(16) unsigned char stage[(6 + 3 + 1) * 256 * DEC_CELLS];
         uint2 *sB = (uint2 *)stage;                                   // 6144 B = 768 x 8
         uint32_t *sC = (uint32_t *)(stage + 6 * 256 * DEC_CELLS);     // 3072 B = 768 x 4
         uint32_t *sM = (uint32_t *)(stage + 9 * 256 * DEC_CELLS);     // 1024 B = 256 x 4
@@ -185,6 +189,10 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
             }
             mk[k] = lM[lc];
         }
+        if (((uintptr_t)VMap & 15) == 0) {
+            __syncthreads();
+            vt = (float *)stage + 3 * 64 * DEC_CELLS * (threadIdx.x >> 6);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < DEC_CELLS; k++) {                   // all loads first
@@ -206,13 +214,28 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
         int i = (int)(cell / (size_t)m), j = (int)(cell % (size_t)m);
         BumpCell o = decode_cell(b[k][0], b[k][1], b[k][2], c[k][0], c[k][1], c[k][2], mk[k], P, (float)i, (float)j, unorm);
         // streaming outputs: written once, never re-read by this kernel
-        DEC_ST(o.v.x, VMap + 3 * cell);
-        DEC_ST(o.v.y, VMap + 3 * cell + 1);
-        DEC_ST(o.v.z, VMap + 3 * cell + 2);
         typedef float vfloat4 __attribute__((ext_vector_type(4)));
+        if (vt) {
+            const int lc = (int)(threadIdx.x & 63) + 64 * k;
+            vt[3 * lc] = o.v.x; vt[3 * lc + 1] = o.v.y; vt[3 * lc + 2] = o.v.z;
+        } else {
+            DEC_ST(o.v.x, VMap + 3 * cell);
+            DEC_ST(o.v.y, VMap + 3 * cell + 1);
+            DEC_ST(o.v.z, VMap + 3 * cell + 2);
+        }
         vfloat4 cv = {o.c.x, o.c.y, o.c.z, o.c.w}, kv = {o.k.x, o.k.y, o.k.z, o.k.w};
         DEC_ST(cv, (vfloat4 *)(RGBA + 4 * cell));
         DEC_ST(kv, (vfloat4 *)(MaskOut + 4 * cell));
+    }
+    if (vt) {                                                   // workgroup-uniform; the region is this wave's own
+        typedef float vfloat4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int lane = threadIdx.x & 63;
+        vfloat4 *dst = (vfloat4 *)(VMap + 3 * (base - lane));   // first cell of the wave: a multiple of 256, 3 KB apart
+#pragma unroll
+        for (int q = 0; q < 3 * DEC_CELLS / 4; q++) DEC_ST(((const vfloat4 *)vt)[lane + 64 * q], dst + lane + 64 * q);
     }
 }
 
