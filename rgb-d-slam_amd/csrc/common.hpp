@@ -90,6 +90,8 @@ __device__ __forceinline__ int f2i_rd(float x) {
 }
 
 struct F3 { float x, y, z; };
+// address space of global memory, for pointers whose origin the compiler cannot see (fetched from tables)
+#define GLOBAL_AS __attribute__((address_space(1)))
 __device__ __forceinline__ F3 ld3(const float *p, size_t idx) {
     F3 r; r.x = p[3 * idx]; r.y = p[3 * idx + 1]; r.z = p[3 * idx + 2]; return r;
 }

@@ -144,12 +144,14 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
     const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * DEC_CELLS) + (threadIdx.x & 63);
     const BumpParam P = load_param(ParamTab[plane]);
     auto unorm = [&](uint8_t x) { return lut[x]; };
-    const uint16_t *__restrict__ Bump = BumpTab[plane];
-    const uint8_t *__restrict__ RGBb = RGBTab[plane];
-    const uint8_t *__restrict__ Maskb = MaskTab[plane];
-    float *__restrict__ VMap = VMapTab[plane];
-    float *__restrict__ RGBA = RGBATab[plane];
-    float *__restrict__ MaskOut = MaskOutTab[plane];
+    // (pointers fetched from a table are generic to the compiler: said to be global, they get global_load / global_store
+    // instead of flat_* instructions)
+    const GLOBAL_AS uint16_t *__restrict__ Bump = (const GLOBAL_AS uint16_t *)BumpTab[plane];
+    const GLOBAL_AS uint8_t *__restrict__ RGBb = (const GLOBAL_AS uint8_t *)RGBTab[plane];
+    const GLOBAL_AS uint8_t *__restrict__ Maskb = (const GLOBAL_AS uint8_t *)MaskTab[plane];
+    GLOBAL_AS float *__restrict__ VMap = (GLOBAL_AS float *)VMapTab[plane];
+    GLOBAL_AS float *__restrict__ RGBA = (GLOBAL_AS float *)RGBATab[plane];
+    GLOBAL_AS float *__restrict__ MaskOut = (GLOBAL_AS float *)MaskOutTab[plane];
     uint16_t b[DEC_CELLS][3];
     uint8_t c[DEC_CELLS][3], mk[DEC_CELLS];
     // The 10 input bytes of a cell sit in three byte streams (6 + 3 + 1): read cell by cell they cost 7 narrow strided
@@ -164,14 +166,15 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
     __shared__ __align__(16) unsigned char stage[12 * 256 * DEC_CELLS];
     float *vt = nullptr;
     if (wide) {
-        uint2 *sB = (uint2 *)stage;                                   // 6144 B = 768 x 8
+        typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+        vu2 *sB = (vu2 *)stage;                                   // 6144 B = 768 x 8
         uint32_t *sC = (uint32_t *)(stage + 6 * 256 * DEC_CELLS);     // 3072 B = 768 x 4
         uint32_t *sM = (uint32_t *)(stage + 9 * 256 * DEC_CELLS);     // 1024 B = 256 x 4
-        const uint2 *gB = (const uint2 *)(Bump + 3 * wg_cell0);
-        const uint32_t *gC = (const uint32_t *)(RGBb + 3 * wg_cell0);
-        const uint32_t *gM = (const uint32_t *)(Maskb + wg_cell0);
+        const GLOBAL_AS vu2 *gB = (const GLOBAL_AS vu2 *)(Bump + 3 * wg_cell0);
+        const GLOBAL_AS uint32_t *gC = (const GLOBAL_AS uint32_t *)(RGBb + 3 * wg_cell0);
+        const GLOBAL_AS uint32_t *gM = (const GLOBAL_AS uint32_t *)(Maskb + wg_cell0);
         const int t = threadIdx.x;
-        uint2 rb0 = gB[t], rb1 = gB[t + 256], rb2 = gB[t + 512];
+        vu2 rb0 = gB[t], rb1 = gB[t + 256], rb2 = gB[t + 512];
         uint32_t rc0 = gC[t], rc1 = gC[t + 256], rc2 = gC[t + 512], rm = gM[t];
         sB[t] = rb0; sB[t + 256] = rb1; sB[t + 512] = rb2;
         sC[t] = rc0; sC[t + 256] = rc1; sC[t + 512] = rc2;
@@ -224,8 +227,8 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
             DEC_ST(o.v.z, VMap + 3 * cell + 2);
         }
         vfloat4 cv = {o.c.x, o.c.y, o.c.z, o.c.w}, kv = {o.k.x, o.k.y, o.k.z, o.k.w};
-        DEC_ST(cv, (vfloat4 *)(RGBA + 4 * cell));
-        DEC_ST(kv, (vfloat4 *)(MaskOut + 4 * cell));
+        DEC_ST(cv, (GLOBAL_AS vfloat4 *)(RGBA + 4 * cell));
+        DEC_ST(kv, (GLOBAL_AS vfloat4 *)(MaskOut + 4 * cell));
     }
     if (vt) {                                                   // workgroup-uniform; the region is this wave's own
         typedef float vfloat4 __attribute__((ext_vector_type(4)));
@@ -233,7 +236,7 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int lane = threadIdx.x & 63;
-        vfloat4 *dst = (vfloat4 *)(VMap + 3 * (base - lane));   // first cell of the wave: a multiple of 256, 3 KB apart
+        GLOBAL_AS vfloat4 *dst = (GLOBAL_AS vfloat4 *)(VMap + 3 * (base - lane));   // first cell of the wave: a multiple of 256, 3 KB apart
 #pragma unroll
         for (int q = 0; q < 3 * DEC_CELLS / 4; q++) DEC_ST(((const vfloat4 *)vt)[lane + 64 * q], dst + lane + 64 * q);
     }
