@@ -533,7 +533,7 @@ struct IcpLoopArgs {
 #endif
 };
 
-__global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(3)))
 void k_icp_loop(IcpLoopArgs L) {
     ICP_SHARED_DECL(S);
     __shared__ int next_step;
