@@ -180,7 +180,7 @@ extern "C" int rgbdslam_profile_hbm_stream(rgbdslam_ctx *ctx, void *dst, const v
     if (((uintptr_t)dst | (uintptr_t)src) & 15) return RGBDSLAM_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n16 = bytes / 16;
-    if ((n16 + 255) / 256 > 0x7FFFFFFFu) return RGBDSLAM_E_LIMIT;
+    if (n16 > 0xFFFFFF00ull) return RGBDSLAM_E_LIMIT;          // one thread per word: a grid holds fewer than 2^32 threads (64 GiB)
     const unsigned grid = (unsigned)((n16 + 255) / 256);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
