@@ -339,6 +339,16 @@ int rgbdslam_raster_clear(rgbdslam_ctx *ctx, uint64_t *zbuf, int n, int m);
 int rgbdslam_predict_raster(rgbdslam_ctx *ctx, float *tex, uint64_t *zbuf, const float *VMap,
                             const float *RGBD, const uint32_t *indices, float thresh,
                             float znear, float zfar, int n, int m);
+/* No counterpart in the reference: rgbdslam_predict_raster for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same kernels, same result, but the z-buffer
+ * is a static device array inside the library (one copy per GPU, 8 bytes x RGBDSLAM_NOALLOC_MAX_PIXELS = 16.6 MB, held
+ * until the process ends; its address on a GPU is resolved by rgbdslam_create on that GPU) instead of a caller
+ * workspace.  The call itself performs no hipMalloc / hipFree / allocating library call.  n * m beyond
+ * RGBDSLAM_NOALLOC_MAX_PIXELS returns RGBDSLAM_E_LIMIT.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two streams, two contexts) race -- serialise them. */
+#define RGBDSLAM_NOALLOC_MAX_PIXELS (1920 * 1080)
+int rgbdslam_predict_raster_noalloc(rgbdslam_ctx *ctx, float *tex, const float *VMap, const float *RGBD,
+                                    const uint32_t *indices, float thresh, float znear, float zfar, int n, int m);
 /* Kernel.cuh:18  void ReadFrame_cu(float *Vmap, float *RGBD, float *NMap, cudaArray *Array, int n, int m)
  * The GL texture becomes the plain f32x4 buffer written by rgbdslam_predict_raster. */
 int rgbdslam_read_frame(rgbdslam_ctx *ctx, float *VMap, float *RGBD, const float *tex, int n, int m);

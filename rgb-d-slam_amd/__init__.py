@@ -229,6 +229,49 @@ class Context:
     def raster_clear(self, zbuf, n, m):
         _chk(self.lib.rgbdslam_raster_clear(self._h, _ptr(zbuf), n, m), "raster_clear")
 
+    # -- the remaining operator functions of the reference headers (csrc/compat.hip) --
+    def merge_depth_kinect(self, rgbd, depth, rgb, mask, n, m):
+        _chk(self.lib.rgbdslam_merge_depth_kinect(self._h, _ptr(rgbd), _ptr(depth), _ptr(rgb), _ptr(mask), n, m), "merge_depth_kinect")
+
+    def gpu_add_zbuff_kinect(self, depth, rgb_in, rgbd, n, m):
+        _chk(self.lib.rgbdslam_gpu_add_zbuff_kinect(self._h, _ptr(depth), _ptr(rgb_in), _ptr(rgbd), n, m), "gpu_add_zbuff_kinect")
+
+    def gpu_cpy(self, img, pitch, rgb, n, m):
+        _chk(self.lib.rgbdslam_gpu_cpy(self._h, _ptr(img), C.c_size_t(pitch), _ptr(rgb), n, m), "gpu_cpy")
+
+    def map_data_2_vbo(self, color, depth, coord, vmap, rgb, n, m):
+        _chk(self.lib.rgbdslam_map_data_2_vbo(self._h, _ptr(color), _ptr(depth), _ptr(coord), _ptr(vmap), _ptr(rgb), n, m), "map_data_2_vbo")
+
+    def vote_plan(self, label, vmap, centers, count, pose, nb, n, m):
+        _chk(self.lib.rgbdslam_vote_plan(self._h, _ptr(label), _ptr(vmap), _ptr(centers), _ptr(count), _host16(pose), nb, n, m), "vote_plan")
+
+    def affect_plan(self, label, buff, n, m):
+        _chk(self.lib.rgbdslam_affect_plan(self._h, _ptr(label), _ptr(buff), n, m), "affect_plan")
+
+    def overlap(self, bump, mask, param, param_in, n, m, N_prim, M_prim):
+        ratio = C.c_float()
+        cnt = (C.c_uint32 * 2)()
+        _chk(self.lib.rgbdslam_overlap(self._h, _ptr(bump), _ptr(mask), _ptr(param), _ptr(param_in), n, m, N_prim, M_prim,
+                                       C.byref(ratio), cnt), "overlap")
+        return ratio.value, (cnt[0], cnt[1])
+
+    def table_store(self, tab, ptr, indx):
+        _chk(self.lib.rgbdslam_table_store(self._h, _ptr(tab), _ptr(ptr), indx), "table_store")
+
+    def update_cu(self, bump_tab, rgb_tab, mask_tab, param_tab, vmap, rgbd, mask, label, pose, N_prim, M_prim, n, m, nb_planes):
+        _chk(self.lib.rgbdslam_update_cu(self._h, _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab), _ptr(param_tab), _ptr(vmap),
+                                         _ptr(rgbd), _ptr(mask), _ptr(label), _host16(pose), N_prim, M_prim, n, m, nb_planes),
+             "update_cu")
+
+    def segment_cu(self, label, vmap, nmap, pose, eq, nb, n, m, eps=0.1, alpha=0.9):
+        _chk(self.lib.rgbdslam_segment_cu(self._h, _ptr(label), _ptr(vmap), _ptr(nmap), _host16(pose), _ptr(eq), nb,
+                                          C.c_float(eps), C.c_float(alpha), n, m), "segment_cu")
+
+    def predict_raster_noalloc(self, tex, vmap, rgbd, indices, n, m, thresh=0.1, znear=0.5, zfar=10.0):
+        _chk(self.lib.rgbdslam_predict_raster_noalloc(self._h, _ptr(tex), _ptr(vmap), _ptr(rgbd), _ptr(indices),
+                                                      C.c_float(thresh), C.c_float(znear), C.c_float(zfar), n, m),
+             "predict_raster_noalloc")
+
     def predict_raster(self, tex, zbuf, vmap, rgbd, indices, n, m, thresh=0.1, znear=0.5, zfar=10.0):
         _chk(self.lib.rgbdslam_predict_raster(self._h, _ptr(tex), _ptr(zbuf), _ptr(vmap), _ptr(rgbd), _ptr(indices),
                                               C.c_float(thresh), C.c_float(znear), C.c_float(zfar), n, m), "predict_raster")

@@ -67,6 +67,8 @@ void prof_group_end(rgbdslam_ctx *ctx);
     } while (0)
 
 #define HIP_TRY(expr)                                     \
+// predict.hip: resolves the device address of the static z-buffer of rgbdslam_predict_raster_noalloc on `device`
+int raster_noalloc_setup(int device);
     do {                                                  \
         hipError_t _e = (expr);                           \
         if (_e != hipSuccess) return -(int)_e;            \

@@ -23,6 +23,10 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_launches = 0; c->prof_in_group = false;
     *out = c;
     return 0;
+    // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc (predict.hip), resolved here so that
+    // the entry point itself never has to
+    int rc = raster_noalloc_setup(device);
+    if (rc) { delete c; return rc; }
 }
 
 extern "C" int rgbdslam_destroy(rgbdslam_ctx *ctx) {

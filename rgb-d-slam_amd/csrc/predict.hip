@@ -2,6 +2,7 @@
 // the compute rasteriser that replaces the reference's OpenGL GL_QUADS pass, read-back to vertex
 // maps, mask/label re-projection and the plane-label growing passes.
 #include "device_fns.hpp"
+#include <mutex>
 
 // ---- D1/Kernel.cu:345-379 TransformVertexMapKernel --------------------------------------------
 __global__ void k_transform_vertex_map(PoseV P, float *__restrict__ VMap, float *__restrict__ RGBD, int n, int m) {
@@ -162,6 +163,47 @@ extern "C" int rgbdslam_predict_raster(rgbdslam_ctx *ctx, float *tex, uint64_t *
                        indices, thresh, ctx->calib, znear, zfar, n, m);
     KLAUNCH(ctx, k_raster_resolve, grid2d(n, m), block2d(), tex, (unsigned long long *)zbuf, VMap,
                        RGBD, indices, ctx->calib, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// ---- the one entry point that allocates nothing (no counterpart in the reference) ---------------------------------
+// rgbdslam_predict_raster with the z-buffer taken from a file-scope device array instead of a caller workspace, for
+// callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc).  Every GPU the
+// library runs on holds its own copy of the array (16.6 MB) at its own address until the process ends; `scratch` is
+// only the host-side stand-in of that symbol, so host code never passes it anywhere: the device address is resolved
+// once per device with hipGetSymbolAddress (below) and only that pointer is used.
+#define RASTER_NOALLOC_MAX_PIXELS (1920 * 1080)
+#define RASTER_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned long long scratch[RASTER_NOALLOC_MAX_PIXELS];
+static std::mutex g_scratch_mutex;
+static unsigned long long *g_scratch_ptr[RASTER_NOALLOC_MAX_DEVICES];   // per device: that GPU's copy of `scratch`
+
+// Called from rgbdslam_create (the library's init call) with `device` current; idempotent.
+int raster_noalloc_setup(int device) {
+    if (device < 0 || device >= RASTER_NOALLOC_MAX_DEVICES) return RGBDSLAM_E_LIMIT;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return 0;
+    HIP_TRY(hipSetDevice(device));
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return -(int)hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = (unsigned long long *)ptr;
+    return 0;
+}
+
+extern "C" int rgbdslam_predict_raster_noalloc(rgbdslam_ctx *ctx, float *tex, const float *VMap, const float *RGBD,
+                                               const uint32_t *indices, float thresh, float znear, float zfar, int n, int m) {
+    if (!ctx || !tex || !VMap || !RGBD || n < 2 || m < 2) return RGBDSLAM_E_ARG;
+    if ((size_t)n * m > (size_t)RASTER_NOALLOC_MAX_PIXELS) return RGBDSLAM_E_LIMIT;   // beyond the static z-buffer
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    if (ctx->device < 0 || ctx->device >= RASTER_NOALLOC_MAX_DEVICES) return RGBDSLAM_E_LIMIT;
+    unsigned long long *zbuf = g_scratch_ptr[ctx->device];   // resolved by rgbdslam_create on this device
+    if (!zbuf) return RGBDSLAM_E_STATE;
+    // the array keeps the last call's contents (an aborted call could leave claimed words): the words this call
+    // uses start at "empty" whatever ran before
+    HIP_TRY(hipMemsetAsync(zbuf, 0xFF, sizeof(unsigned long long) * (size_t)n * m, ctx->stream));
+    KLAUNCH(ctx, k_raster_draw, grid2d(n - 1, m - 1), block2d(), zbuf, VMap, indices, thresh, ctx->calib, znear, zfar, n, m);
+    KLAUNCH(ctx, k_raster_resolve, grid2d(n, m), block2d(), tex, zbuf, VMap, RGBD, indices, ctx->calib, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
