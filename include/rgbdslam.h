@@ -405,6 +405,45 @@ int rgbdslam_detect_regions(rgbdslam_ctx *ctx, const float *NMap, const float *V
                             double canny_low, double canny_high, float thresh_discont, uint8_t thresh_edge,
                             int32_t *blob, int32_t *sizes, int32_t *work_labels, uint8_t *work_bytes, int n, int m);
 
+/* ---- the rest of the reference's operator headers: everything else its unchanged host code calls ---------------------
+ * (so that integration/rgbdslam_shim.cpp defines every symbol Frame.cpp / Graph.cpp / RG.cpp reference) */
+/* Kernel.cuh:22  void MergeDepthKinect(float *RGB_predicted, unsigned short *depth, float *RGB, unsigned char *mask, int n, int m)
+ * (Kernel.cu:528-614; live-Kinect layout: depth[(n-1-i)*m + (m-1-j)], no pitch; Frame.cpp:315) */
+int rgbdslam_merge_depth_kinect(rgbdslam_ctx *ctx, float *RGBD_predicted, const uint16_t *depth, const float *RGB,
+                                uint8_t *mask, int n, int m);
+/* Kernel.cuh:36  void gpu_add_zbuffKinect(unsigned short *depth, float *rgb_in, float *rgb, int n, int m)  (Kernel.cu:804-823; Frame.cpp:353) */
+int rgbdslam_gpu_add_zbuff_kinect(rgbdslam_ctx *ctx, const uint16_t *depth, const float *rgb_in, float *RGBD, int n, int m);
+/* Kernel.cuh:28  void gpu_cpy(cv::gpu::DevMem2D_<float> mat, float *rgb, int n, int m)  (Kernel.cu:670-682; RG.cpp:807) on its own,
+ * for callers that keep cv::gpu::Sobel; rgbdslam_intensity_sobel is the fused form */
+int rgbdslam_gpu_cpy(rgbdslam_ctx *ctx, float *img, size_t img_pitch_bytes, const float *rgb, int n, int m);
+/* Kernel.cuh:16  void MapData2VBO_cu(BYTE *d_colorFrame, USHORT *d_depthFrame, LONG *d_colorCoord, float *VMap, float *RGB, int n, int m)
+ * (Kernel.cu:74-121; Frame.cpp:103; BGRA8 colour, LONG = int32).  VMap / RGB are only written where the colour coordinate is valid. */
+int rgbdslam_map_data_2_vbo(rgbdslam_ctx *ctx, const uint8_t *colorFrame, const uint16_t *depthFrame, const int32_t *colorCoord,
+                            float *VMap, float *RGB, int n, int m);
+/* RG.cuh:23  void VotePlan_cu(unsigned char *Label, float *VMap, float *centers, float *count, float *pose, int n, int m)
+ * (RG.cu:508-537,999-1014; RG.cpp:946).  centers (3*nbPlans) and count (nbPlans) are DEVICE buffers that are added to; pose is
+ * a HOST pointer.  The reference's unordered float atomics are replaced by a fixed summation order. */
+int rgbdslam_vote_plan(rgbdslam_ctx *ctx, const uint8_t *Label, const float *VMap, float *centers_dev, float *count_dev,
+                       const float *pose16_host, int nbPlans, int n, int m);
+/* RG.cuh:25  void AffectPlan_cu(unsigned char *Label, int *Buff, int n, int m)  (RG.cu:539-555,1016-1025; RG.cpp:965) */
+int rgbdslam_affect_plan(rgbdslam_ctx *ctx, uint8_t *Label, const int32_t *Buff_dev, int n, int m);
+/* Primitive.cuh:32  float Overlap_cu(unsigned short *Bump, unsigned char *Mask, float *param, float *param_in, int n, int m, int N_prim, int M_prim)
+ * (Primitive.cu:502-556; Graph.cpp:341).  BLOCKING.  counters2 (optional, host): [0] cells landing on the other plane, [1] occupied cells. */
+int rgbdslam_overlap(rgbdslam_ctx *ctx, const uint16_t *Bump, const uint8_t *Mask, const float *param_dev, const float *param_in_dev,
+                     int n, int m, int N_prim, int M_prim, float *ratio, uint32_t *counters2);
+/* RG.cuh:27-29  void Affect(float **Tab, float *in, int indx) / AffectChar / AffectShort  (RG.cu:557-567,1027-1049; Graph.cpp:64-68):
+ * Tab[indx] = ptr in a device pointer table.  BLOCKING, like the reference's one-thread kernels. */
+int rgbdslam_table_store(rgbdslam_ctx *ctx, void **tab_dev, const void *ptr, int indx);
+/* Primitive.cuh:23-24  Update_cu with exactly the reference's arguments: rgbdslam_update with the claim slabs (one u64 per cell and
+ * plane, allocated on first use and kept in the context) and the call stamp owned by the library.  nb_planes = valid table entries. */
+#define RGBDSLAM_COMPAT_MAX_PLANES 255
+int rgbdslam_update_cu(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                       const float *VMap, const float *RGBD, const uint8_t *Mask, const uint8_t *Label,
+                       const float *pose16_host, int N_prim, int M_prim, int n, int m, int nb_planes);
+/* RG.cuh:11  Segment_cu with exactly the reference's arguments: rgbdslam_segment with the swap image owned by the library */
+int rgbdslam_segment_cu(rgbdslam_ctx *ctx, uint8_t *Label, const float *VMap, const float *NMap, const float *pose16_host,
+                        const float *Equations_dev, int nbPlans, float epsilon, float alpha, int n, int m);
+
 #ifdef __cplusplus
 }
 #endif

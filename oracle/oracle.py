@@ -42,6 +42,7 @@ def lib():
                 build()
             h = C.CDLL(path)
             h.orc_det6.restype = C.c_float
+            h.orc_overlap.restype = C.c_float
             h.orc_slam_create.restype = C.c_void_p
             h.orc_slam_buffer.restype = C.c_void_p
             _LIBS[name] = h
@@ -441,3 +442,58 @@ def detect_regions(nmap, vmap, label=None):
     binary = (erode_ellipse5(img2) > 0).astype(np.uint8)
     blob, sizes = find_blobs(binary)
     return blob, sizes, binary
+
+
+# ---- the remaining operator functions of the reference headers (csrc/compat.hip) ---------------------
+def merge_depth_kinect(rgbd, depth, rgb, mask, calib):
+    n, m = depth.shape
+    rgbd = _f32(rgbd).copy()
+    mask = np.ascontiguousarray(mask, np.uint8).copy()
+    lib().orc_merge_depth_kinect(_p(rgbd), _p(np.ascontiguousarray(depth, np.uint16)), _p(_f32(rgb)), _p(mask), _p(_f32(calib)), n, m)
+    return rgbd, mask
+
+
+def add_zbuff_kinect(depth, rgb, calib):
+    n, m = depth.shape
+    out = np.empty((n, m, 4), np.float32)
+    lib().orc_add_zbuff_kinect(_p(np.ascontiguousarray(depth, np.uint16)), _p(_f32(rgb)), _p(out), _p(_f32(calib)), n, m)
+    return out
+
+
+def gpu_cpy(rgb):
+    n, m, _ = rgb.shape
+    out = np.empty((n, m), np.float32)
+    lib().orc_gpu_cpy(_p(out), C.c_size_t(m), _p(_f32(rgb)), n, m)
+    return out
+
+
+def map_data_2_vbo(color_bgra, depth, coord, calib):
+    n, m = depth.shape
+    v = np.zeros((n, m, 3), np.float32)
+    rgb = np.zeros((n, m, 3), np.float32)
+    lib().orc_map_data_2_vbo(_p(np.ascontiguousarray(color_bgra, np.uint8)), _p(np.ascontiguousarray(depth, np.uint16)),
+                             _p(np.ascontiguousarray(coord, np.int32)), _p(v), _p(rgb), _p(_f32(calib)), n, m)
+    return v, rgb
+
+
+def vote_plan(label, vmap, pose, nb, centers=None, count=None):
+    n, m = label.shape
+    centers = np.zeros(3 * nb, np.float32) if centers is None else _f32(centers).copy()
+    count = np.zeros(nb, np.float32) if count is None else _f32(count).copy()
+    lib().orc_vote_plan(_p(np.ascontiguousarray(label, np.uint8)), _p(_f32(vmap)), _p(centers), _p(count), _p(_f32(pose)), nb, n, m)
+    return centers, count
+
+
+def affect_plan(label, buff):
+    n, m = label.shape
+    lab = np.ascontiguousarray(label, np.uint8).copy()
+    lib().orc_affect_plan(_p(lab), _p(np.ascontiguousarray(buff, np.int32)), n, m)
+    return lab
+
+
+def overlap(bump, mask, param, param_in, N_prim, M_prim):
+    n, m = mask.shape
+    cnt = np.zeros(2, np.uint32)
+    r = lib().orc_overlap(_p(np.ascontiguousarray(bump, np.uint16)), _p(np.ascontiguousarray(mask, np.uint8)), _p(_f32(param)),
+                          _p(_f32(param_in)), n, m, N_prim, M_prim, _p(cnt))
+    return float(r), cnt

@@ -583,6 +583,38 @@ int orc_align_gauss_newton(const orc_icp_params *prm, const float *intr,
 /* Stage 4: fusion                                                                       */
 /* ===================================================================================== */
 
+/* one pixel of MergeDepthOffProcess / MergeDepthKinectProcess (Kernel.cu:440-526, 528-611): the two differ only in
+ * where the raw depth sample d comes from */
+static void merge_one(float *px, uint16_t d, const float *rgb, uint8_t *mask, float ds, float factor) {
+    float dv = (ds / factor) * (float)d;                                             /* Kernel.cu:453 / 541 */
+    float dp = (float)((double)px[3] * MAX_DEPTH);                                   /* :454 */
+    float mv = (float)((double)(float)*mask - 10.0);                                 /* :455 */
+    float mt = 1.0f;
+    px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
+    if ((double)dv < 0.1) return;                                                    /* :467 */
+    if ((double)dp < 0.1 || fabs((double)mv + 9.0) < 0.01) {                         /* :477 */
+        px[3] = (float)((double)dv / MAX_DEPTH);
+        *mask = (uint8_t)((double)mt + 10.0);
+        return;
+    }
+    if ((double)dv < ((double)dp - MAXTOLERANCE)) {                                  /* :489 */
+        px[3] = (float)((double)dv / MAX_DEPTH);
+        *mask = (uint8_t)((double)mt + 10.0);
+        return;
+    }
+    double mx = 1.0 > 1.0 * (double)dv ? 1.0 : 1.0 * (double)dv;
+    if ((double)dv > ((double)dp + mx * MAXTOLERANCE)) {                             /* :502 */
+        *mask = 10;
+        return;
+    }
+    float am = fabsf(mv);
+    float avg = (dv * mt + am * dp) / (mt + am);                                     /* :512 float */
+    px[3] = (float)((double)avg / MAX_DEPTH);
+    double mk = (double)(mt + am) + 10.0;
+    if (mk > 255.0) mk = 255.0;
+    *mask = (uint8_t)mk;                                                             /* :520 */
+}
+
 void orc_merge_depth_off(float *RGBD, const uint16_t *depth, size_t pitch, const float *RGB,
                          uint8_t *mask, const float *calib, int n, int m) {
     float ds = calib[9], factor = calib[10];
@@ -590,33 +622,19 @@ void orc_merge_depth_off(float *RGBD, const uint16_t *depth, size_t pitch, const
     for (int i = 0; i < n; i++)
         for (int j = 0; j < m; j++) {
             size_t idx = (size_t)i * m + j;
-            float dv = (ds / factor) * (float)depth[(size_t)(n - i - 1) * pitch + j];   /* Kernel.cu:453 */
-            float dp = (float)((double)RGBD[4 * idx + 3] * MAX_DEPTH);                   /* :454 */
-            float mv = (float)((double)(float)mask[idx] - 10.0);                         /* :455 */
-            float mt = 1.0f;
-            RGBD[4 * idx] = RGB[3 * idx]; RGBD[4 * idx + 1] = RGB[3 * idx + 1]; RGBD[4 * idx + 2] = RGB[3 * idx + 2];
-            if ((double)dv < 0.1) continue;                                              /* :467 */
-            if ((double)dp < 0.1 || fabs((double)mv + 9.0) < 0.01) {                     /* :477 */
-                RGBD[4 * idx + 3] = (float)((double)dv / MAX_DEPTH);
-                mask[idx] = (uint8_t)((double)mt + 10.0);
-                continue;
-            }
-            if ((double)dv < ((double)dp - MAXTOLERANCE)) {                              /* :489 */
-                RGBD[4 * idx + 3] = (float)((double)dv / MAX_DEPTH);
-                mask[idx] = (uint8_t)((double)mt + 10.0);
-                continue;
-            }
-            double mx = 1.0 > 1.0 * (double)dv ? 1.0 : 1.0 * (double)dv;
-            if ((double)dv > ((double)dp + mx * MAXTOLERANCE)) {                         /* :502 */
-                mask[idx] = 10;
-                continue;
-            }
-            float am = fabsf(mv);
-            float avg = (dv * mt + am * dp) / (mt + am);                                 /* :512 float */
-            RGBD[4 * idx + 3] = (float)((double)avg / MAX_DEPTH);
-            double mk = (double)(mt + am) + 10.0;
-            if (mk > 255.0) mk = 255.0;
-            mask[idx] = (uint8_t)mk;                                                     /* :520 */
+            merge_one(RGBD + 4 * idx, depth[(size_t)(n - i - 1) * pitch + j], RGB + 3 * idx, mask + idx, ds, factor);
+        }
+}
+
+/* Kernel.cu:528-614 MergeDepthKinectKernel: live-Kinect depth layout, rows AND columns flipped, no pitch (:541) */
+void orc_merge_depth_kinect(float *RGBD, const uint16_t *depth, const float *RGB, uint8_t *mask,
+                            const float *calib, int n, int m) {
+    float ds = calib[9], factor = calib[10];
+    #pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            size_t idx = (size_t)i * m + j;
+            merge_one(RGBD + 4 * idx, depth[(size_t)(n - 1 - i) * m + (m - 1 - j)], RGB + 3 * idx, mask + idx, ds, factor);
         }
 }
 
@@ -1048,6 +1066,114 @@ void orc_add_zbuff_off(const uint16_t *depth, size_t pitch, const float *rgb_in,
             RGBD[4 * idx] = rgb_in[3 * idx]; RGBD[4 * idx + 1] = rgb_in[3 * idx + 1]; RGBD[4 * idx + 2] = rgb_in[3 * idx + 2];
             RGBD[4 * idx + 3] = ((double)z > MAX_DEPTH || (double)z < 0.0) ? 0.0f : (float)((double)z / MAX_DEPTH);
         }
+}
+
+/* Kernel.cu:804-823 AddZBUFFKinectKernel: depth[idx], neither flipped nor pitched */
+void orc_add_zbuff_kinect(const uint16_t *depth, const float *rgb_in, float *RGBD, const float *calib, int n, int m) {
+    float ds = calib[9], factor = calib[10];
+    #pragma omp parallel for schedule(static)
+    for (size_t idx = 0; idx < (size_t)n * m; idx++) {
+        float z = (ds / factor) * (float)depth[idx];
+        RGBD[4 * idx] = rgb_in[3 * idx]; RGBD[4 * idx + 1] = rgb_in[3 * idx + 1]; RGBD[4 * idx + 2] = rgb_in[3 * idx + 2];
+        RGBD[4 * idx + 3] = ((double)z > MAX_DEPTH || (double)z < 0.0) ? 0.0f : (float)((double)z / MAX_DEPTH);
+    }
+}
+
+/* Kernel.cu:670-682 CpyKernel: grey image into a pitched float matrix (pitch in floats) */
+void orc_gpu_cpy(float *img, size_t pitch, const float *rgb, int n, int m) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            size_t idx = (size_t)i * m + j;
+            img[(size_t)i * pitch + j] = (float)((double)((rgb[3 * idx + 2] + rgb[3 * idx + 1]) + rgb[3 * idx]) / 3.0);
+        }
+}
+
+/* Kernel.cu:74-121 MapData2VBOKernel (live Kinect frame -> VMap / RGB, both flipped; LONG is 32 bit on the reference's
+ * platform).  VMap and RGB must be zeroed by the caller (Frame.cpp:95-97). */
+void orc_map_data_2_vbo(const uint8_t *color_bgra, const uint16_t *depth, const int32_t *color_coord, float *VMap,
+                        float *RGB, const float *calib, int n, int m) {
+    float fx = calib[0], fy = calib[1], cx = calib[2], cy = calib[3];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            size_t idx = (size_t)i * m + j, idx_new = (size_t)(n - 1 - i) * m + (m - 1 - j);
+            float z = ((float)(-calib[9]) * (float)depth[idx]) / calib[10];         /* :95 */
+            float x = (((float)j - cx) * z) / fx;                                   /* :96 */
+            float y = (((float)i - cy) * z) / fy;
+            int32_t u = color_coord[2 * idx], v = color_coord[2 * idx + 1];
+            if (u >= 0 && u < m && v >= 0 && v < n && (double)z > -MAX_DEPTH) {     /* :104 */
+                size_t ci = (size_t)v * ((size_t)m * 4) + (size_t)u * 4;
+                VMap[3 * idx_new] = x; VMap[3 * idx_new + 1] = y; VMap[3 * idx_new + 2] = z;
+                RGB[3 * idx_new]     = (float)((double)(float)color_bgra[ci + 2] / 255.0);
+                RGB[3 * idx_new + 1] = (float)((double)(float)color_bgra[ci + 1] / 255.0);
+                RGB[3 * idx_new + 2] = (float)((double)(float)color_bgra[ci] / 255.0);
+            }
+        }
+}
+
+/* RG.cu:508-537 VotePlanKernel.  The reference adds with unordered float atomics, so its sums are scheduler dependent;
+ * defined order here (and in the HIP kernel): per label, a row's contributions are added left to right starting from 0,
+ * and the row sums are added top to bottom starting from 0.  count is exact either way. */
+void orc_vote_plan(const uint8_t *Label, const float *VMap, float *centers, float *count, const float *pose,
+                   int nbPlans, int n, int m) {
+    for (int L = 0; L < nbPlans; L++) {
+        float s[3] = {0.0f, 0.0f, 0.0f}, cnt = 0.0f;
+        for (int i = 0; i < n; i++) {
+            float r[3] = {0.0f, 0.0f, 0.0f}, rc = 0.0f;
+            int any = 0;
+            for (int j = 0; j < m; j++) {
+                size_t idx = (size_t)i * m + j;
+                if (Label[idx] != L + 1) continue;
+                float l0 = VMap[3 * idx], l1 = VMap[3 * idx + 1], l2 = VMap[3 * idx + 2];
+                r[0] = r[0] + (((pose[0] * l0 + pose[4] * l1) + pose[8] * l2) + pose[12]);   /* :526-528 */
+                r[1] = r[1] + (((pose[1] * l0 + pose[5] * l1) + pose[9] * l2) + pose[13]);
+                r[2] = r[2] + (((pose[2] * l0 + pose[6] * l1) + pose[10] * l2) + pose[14]);
+                rc = rc + 1.0f;
+                any = 1;
+            }
+            if (any) { s[0] = s[0] + r[0]; s[1] = s[1] + r[1]; s[2] = s[2] + r[2]; cnt = cnt + rc; }
+        }
+        if (cnt > 0.0f) { centers[3 * L] += s[0]; centers[3 * L + 1] += s[1]; centers[3 * L + 2] += s[2]; count[L] += cnt; }
+    }
+}
+
+/* RG.cu:539-555 AffectPlanKernel: label remap through a LUT */
+void orc_affect_plan(uint8_t *Label, const int32_t *Buff, int n, int m) {
+    for (size_t idx = 0; idx < (size_t)n * m; idx++)
+        if (Label[idx] != 0) Label[idx] = (uint8_t)Buff[Label[idx] - 1];
+}
+
+/* Primitive.cu:502-556,795-... Overlap_cu: share of plane `param`'s occupied cells that fall on plane `param_in`
+ * (distance <= EPSILON = 0.1, cudaTypes.cuh:48) inside its N_prim x M_prim image; 1 when nothing is occupied */
+float orc_overlap(const uint16_t *Bump, const uint8_t *Mask, const float *param, const float *param_in, int n, int m,
+                  int N_prim, int M_prim, uint32_t *counter2) {
+    uint32_t c0 = 0, c1 = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            size_t idx = (size_t)i * m + j;
+            if (Mask[idx] < 11) continue;
+            float s0 = (float)((double)(float)Bump[3 * idx] / 60000.0), s1 = (float)((double)(float)Bump[3 * idx + 1] / 60000.0);
+            float x = (float)((double)((float)i + s0) * 2.0 / (double)param[4] + (double)param[6]);
+            float y = (float)((double)((float)j + s1) * 2.0 / (double)param[5] + (double)param[7]);
+            float d = (float)((double)param[3] + (((double)(float)Bump[3 * idx + 2] / 2000.0) - 15.0));
+            float pt[3];
+            pt[0] = (x * param[8] + y * param[11]) + d * param[0];
+            pt[1] = (x * param[9] + y * param[12]) + d * param[1];
+            pt[2] = (x * param[10] + y * param[13]) + d * param[2];
+            if (pt[0] == 0.0f && pt[1] == 0.0f && pt[2] == 0.0f) continue;
+            c1++;
+            float ed = ((pt[0] * param_in[0] + pt[1] * param_in[1]) + pt[2] * param_in[2]) - param_in[3];
+            if ((double)fabsf(ed) > 0.1) continue;
+            float pa = (pt[0] * param_in[8] + pt[1] * param_in[9]) + pt[2] * param_in[10];
+            float pb = (pt[0] * param_in[11] + pt[1] * param_in[12]) + pt[2] * param_in[13];
+            pa = (float)((double)((pa - param_in[6]) * param_in[4]) / 2.0);
+            pb = (float)((double)((pb - param_in[7]) * param_in[5]) / 2.0);
+            int ii = f2i_rd(pa), jj = f2i_rd(pb);
+            if (ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0) continue;
+            c0++;
+        }
+    if (counter2) { counter2[0] = c0; counter2[1] = c1; }
+    if (c1 == 0) return 1.0f;
+    return (float)c0 / (float)c1;
 }
 
 void orc_init_mask(uint8_t *mask, const float *RGBD, int n, int m) {

@@ -176,4 +176,22 @@ int orc_fit_planes(const int32_t *blob, const int32_t *sizes, const float *VMap,
 /* threads the row loops run on: 1 in the default build, omp_get_max_threads() in librgbdslam_oracle_omp.so */
 int orc_threads(void);
 
+/* ---- the remaining operator functions the reference's host code calls (checker of csrc/compat.hip) ---- */
+/* Kernel.cu:528-614 MergeDepthKinectKernel */
+void orc_merge_depth_kinect(float *RGBD, const uint16_t *depth, const float *RGB, uint8_t *mask, const float *calib, int n, int m);
+/* Kernel.cu:804-823 AddZBUFFKinectKernel */
+void orc_add_zbuff_kinect(const uint16_t *depth, const float *rgb_in, float *RGBD, const float *calib, int n, int m);
+/* Kernel.cu:670-682 CpyKernel (pitch in floats) */
+void orc_gpu_cpy(float *img, size_t pitch, const float *rgb, int n, int m);
+/* Kernel.cu:74-121 MapData2VBOKernel */
+void orc_map_data_2_vbo(const uint8_t *color_bgra, const uint16_t *depth, const int32_t *color_coord, float *VMap, float *RGB,
+                        const float *calib, int n, int m);
+/* RG.cu:508-537 VotePlanKernel, with a defined summation order (rows left to right, then rows top to bottom) */
+void orc_vote_plan(const uint8_t *Label, const float *VMap, float *centers, float *count, const float *pose, int nbPlans, int n, int m);
+/* RG.cu:539-555 AffectPlanKernel */
+void orc_affect_plan(uint8_t *Label, const int32_t *Buff, int n, int m);
+/* Primitive.cu:502-556 + the wrapper's ratio (counter[0] / counter[1], 1 when nothing is occupied) */
+float orc_overlap(const uint16_t *Bump, const uint8_t *Mask, const float *param, const float *param_in, int n, int m, int N_prim,
+                  int M_prim, uint32_t *counter2);
+
 #endif

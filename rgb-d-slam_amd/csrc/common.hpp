@@ -49,7 +49,15 @@ struct rgbdslam_ctx {
     int prof_cap, prof_n;
     int prof_launches;     // launches covered by the recorded event pairs
     bool prof_in_group;    // inside prof_group_begin/end: launches are counted, the group carries the one event pair
+    // compat.hip: work buffers behind the reference-shaped Update_cu / Segment_cu / Overlap_cu (allocated on first use)
+    uint64_t *claim_slab[RGBDSLAM_COMPAT_MAX_PLANES];   // one u64 claim word per Bump cell and plane
+    uint64_t **claim_tab_dev;                           // device copy of claim_slab
+    size_t claim_cells;
+    uint32_t claim_stamp;
+    uint8_t *label_swap; size_t label_swap_px;
+    unsigned int *compat_counter;
 };
+void compat_release(rgbdslam_ctx *ctx);
 
 // Launch on the context's stream; when the kernel's name is the one being profiled, bracket the
 // launch with a HIP event pair recorded on that same stream.
@@ -59,6 +67,8 @@ void prof_end(rgbdslam_ctx *ctx);
 // launch-to-launch behaviour instead of one marker round trip per launch)
 bool prof_group_begin(rgbdslam_ctx *ctx, const char *kname);
 void prof_group_end(rgbdslam_ctx *ctx);
+// predict.hip: resolves the device address of the static z-buffer of rgbdslam_predict_raster_noalloc on `device`
+int raster_noalloc_setup(int device);
 #define KLAUNCH(ctx, kern, grid, block, ...)                                         \
     do {                                                                             \
         bool _prof = (ctx)->prof_name && prof_begin((ctx), #kern);                   \
@@ -67,8 +77,6 @@ void prof_group_end(rgbdslam_ctx *ctx);
     } while (0)
 
 #define HIP_TRY(expr)                                     \
-// predict.hip: resolves the device address of the static z-buffer of rgbdslam_predict_raster_noalloc on `device`
-int raster_noalloc_setup(int device);
     do {                                                  \
         hipError_t _e = (expr);                           \
         if (_e != hipSuccess) return -(int)_e;            \
