@@ -166,11 +166,253 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
                  "note": "k_hbm_stream, one 16-byte word per lane, workgroups in address order, 10 launches; copy counts read + written bytes"}
 
 
+def _max_over_ranks(env, seconds):
+    if env["world"] == 1:
+        return seconds
+    t = env["torch"].tensor([seconds], dtype=env["torch"].float64, device=env["coll_dev"])
+    env["dist"].all_reduce(t, op=env["dist"].ReduceOp.MAX)
+    return float(t.item())
+
+
+def _barrier(env):
+    env["torch"].cuda.synchronize()
+    if env["world"] > 1:
+        env["dist"].barrier()
+    env["torch"].cuda.synchronize()
+
+
+def _profile(lib, ctx_h, kernel, run):
+    lib.rgbdslam_profile_kernel(ctx_h, kernel.encode())
+    run()
+    tot, cnt = C.c_double(), C.c_int()
+    lib.rgbdslam_profile_read(ctx_h, C.byref(tot), C.byref(cnt))
+    lib.rgbdslam_profile_kernel(ctx_h, None)
+    return tot.value, cnt.value
+
+
+def run_planes(args, env):
+    """BASELINE configs[2]: a model of 256 planes x 512x512 Bump cells, partitioned by plane over the ranks.  One step =
+    rank 0 tracks one 640x480 frame (the configs[1] pipeline without planes of its own), labels the merged model frame
+    (16-bit labels, plane membership: detection bypassed as in SURVEY 8d config 2) and BROADCASTS VMap / RGBD / Mask /
+    Label / pose (9.2 MB, the step's only collective); every rank then fuses the frame into the planes it owns
+    (Graph::Update, claim + apply) and decodes them (VertexFromBump).  Total work is fixed: strong scaling."""
+    torch, dist, rank, world, local, pkg, synth = (env[k] for k in ("torch", "dist", "rank", "world", "local", "pkg", "synth"))
+    multigpu = importlib.import_module("rgb-d-slam_amd.multigpu")
+    planes, N, n, m = 256, 512, 480, 640
+    calib = synth.calib_for(n, m)
+    stream = torch.cuda.Stream()
+    lib = pkg.load()
+    with torch.cuda.stream(stream):
+        ctx = pkg.Context(local, stream.cuda_stream)
+        ctx.set_calibration_matrix(calib)
+        shard = multigpu.PlaneShard(ctx, synth.tiled_planes(planes, N), N, rank, world)
+        pack = multigpu.FramePack(n, m)
+        rg = None
+        if rank == 0:
+            pool = synth.sequence(POOL_FRAMES, n, m, calib, noise_sigma=0.001, seed=0)
+            depth_dev = [torch.from_numpy(p[0]).cuda() for p in pool]
+            bgr_dev = [torch.from_numpy(p[1]).cuda() for p in pool]
+            rg = pkg.RG(n, m, calib, device=local, stream=stream.cuda_stream)
+            if world == 1 or "RGBDSLAM_BENCH_DEVICE" not in os.environ:
+                try:
+                    rg.set_icp_loop(bool(args.icp_loop))
+                except RuntimeError:
+                    pass
+        order, k, d = [], 0, 1
+        for _ in range(2 * (args.warmup + args.steps) + 2):
+            order.append(k)
+            if k + d < 0 or k + d >= POOL_FRAMES:
+                d = -d
+            k += d
+        pos = [0]
+        ev = {}
+
+        def step(mark=None):
+            if rank == 0:
+                i = order[pos[0]]
+                pos[0] += 1
+                if mark:
+                    mark("t0")
+                rg.load_frame_device(depth_dev[i], bgr_dev[i])
+                rg.step_async()
+                rg.export_frame(pack.buf, pack.off_vmap, pack.off_rgbd, pack.off_mask, pack.off_hist)
+                shard.label(pack, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0])
+                if mark:
+                    mark("t1")
+            pack.broadcast(0)
+            if mark:
+                mark("t2")
+            shard.fuse_and_decode(pack)
+            if mark:
+                mark("t3")
+
+        for _ in range(1 + args.warmup):
+            step()
+        _barrier(env)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        stream.synchronize()
+        _barrier(env)
+        dt = _max_over_ranks(env, time.perf_counter() - t0)
+        tracked = 0
+        if rank == 0:
+            rg.synchronize()
+            h = rg.history(rg.frames_done() - args.steps, args.steps)
+            tracked = int((h[:, 12] == 1.0).sum())
+            if tracked != args.steps:
+                raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
+        # ---- second pass (untimed): phases by events on rank 0's stream, decode kernel by the library's event hook ----
+        phases = None
+        marks = []
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            marks.append((name, e))
+        reps = min(args.steps, 50)
+        tot_ms, launches = _profile(lib, ctx._h, "k_vertex_from_bump_batch", lambda: [step(mark if rank == 0 else None) for _ in range(reps)])
+        stream.synchronize()
+        if rank == 0:
+            acc = {"track_label_export": 0.0, "broadcast": 0.0, "fuse_decode": 0.0}
+            for q in range(0, len(marks), 4):
+                acc["track_label_export"] += marks[q][1].elapsed_time(marks[q + 1][1])
+                acc["broadcast"] += marks[q + 1][1].elapsed_time(marks[q + 2][1])
+                acc["fuse_decode"] += marks[q + 2][1].elapsed_time(marks[q + 3][1])
+            phases = {k_: round(v / reps * 1e3, 1) for k_, v in acc.items()}
+            phases["unit"] = "us per step on rank 0 (event pairs on its stream, second pass)"
+        cells = (shard.hi - shard.lo) * N * N
+        ev_ms = C.c_double()
+        lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev_ms))
+        avg_ms = max(1e-9, tot_ms / max(1, launches) - ev_ms.value)
+        achieved = 54 * cells / (avg_ms * 1e-3) / 1e9
+        _barrier(env)
+        if rank != 0:
+            ctx.close()
+            return None
+        out = {"metric": "plane-partitioned Bump fusion + decode steps/sec (256 planes x 512x512, one 640x480 frame per step)",
+               "value": round(args.steps / dt, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2]: 256 planes x 512x512 Bump cells tiled over the three planes of the synthetic room "
+                                      "corner; per step rank 0 tracks one 640x480 frame, labels it (u16) and broadcasts VMap/RGBD/Mask/Label/pose "
+                                      "(%d bytes), every rank fuses it into and decodes the planes it owns" % pack.nbytes,
+                          "planes_per_rank": shard.hi - shard.lo, "broadcast_bytes": pack.nbytes, "backend": env["backend"],
+                          "frames_resident_in_hbm": True},
+               "roofline": {"bound": "hbm", "kernel": "k_vertex_from_bump_batch", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": 54 * cells, "avg_launch_us": round(avg_ms * 1e3, 2),
+                            "note": "rank 0's share: 54 B per owned Bump cell per launch"},
+               "phases": phases, "cpu_baseline": None}
+        rg.close()
+        ctx.close()
+        return out
+
+
+def run_rows(args, env):
+    """BASELINE configs[3]: row-sharded ICP on a 1920x1080 pair.  One step = one coarse-to-fine Gauss-Newton alignment
+    (RG::AlignFrameGaussNewton) of the pair from the same start pose; every rank computes the normal equations of its band of
+    8x8-block rows, the 27 partial sums are exchanged every iteration, and every rank runs the identical solve.  Total work
+    is fixed: strong scaling."""
+    torch, dist, rank, world, local, pkg, synth = (env[k] for k in ("torch", "dist", "rank", "world", "local", "pkg", "synth"))
+    multigpu = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m = (args.rows, args.cols) if (args.rows, args.cols) != (480, 640) else (1080, 1920)
+    calib = synth.calib_for(n, m)
+    stream = torch.cuda.Stream()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    with torch.cuda.stream(stream):
+        ctx = pkg.Context(local, stream.cuda_stream)
+        ctx.set_calibration_matrix(calib)
+        R1, t1 = synth.pair_offset_pose()
+        g = {}
+        rng = np.random.default_rng(1)
+        for k, (R, t) in enumerate(((np.eye(3), np.zeros(3)), (R1, t1))):
+            d, c = synth.render(R, t, n, m, calib, noise_sigma=0.001, rng=rng)   # the same pair on every rank (same seed)
+            gd, gc = dev(d), dev(c)
+            v = torch.empty(n, m, 3, device="cuda"); nm = torch.empty(n, m, 3, device="cuda"); rgb = torch.empty(n, m, 3, device="cuda")
+            ctx.vertex_map_kinect(v, gd, 2 * m, n, m)
+            ctx.compute_normal(nm, v, n, m, True)
+            ctx.gpu_cpy_char3(gc, 3 * m, rgb, n, m)
+            g["v%d" % k], g["n%d" % k], g["rgb%d" % k], g["d%d" % k] = v, nm, rgb, gd
+        rgbd0 = torch.empty(n, m, 4, device="cuda")
+        ctx.gpu_add_zbuff_off(g["d0"], 2 * m, g["rgb0"], rgbd0, n, m)
+        gx = torch.empty(n, m, device="cuda"); gy = torch.empty(n, m, device="cuda")
+        ctx.intensity_sobel(g["rgb1"], None, gx, gy, n, m)
+        ctx.alloc_buffers((n + 7) // 8, (m + 7) // 8)
+        prm = pkg.icp_params()
+        aligner = multigpu.ShardedAligner(ctx, prm, n, m, rank, world, exchange=args.exchange)
+        I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+        start = dev(np.concatenate([I, z, I, z]).astype(np.float32))
+        state = start.clone()
+        status = torch.zeros(4, dtype=torch.int32, device="cuda")
+
+        def step():
+            state.copy_(start)
+            aligner.align(g["v1"], g["n1"], g["rgb1"], gx, gy, g["v0"], g["n0"], rgbd0, state, status)
+
+        for _ in range(1 + args.warmup):
+            step()
+        _barrier(env)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        stream.synchronize()
+        _barrier(env)
+        dt = _max_over_ranks(env, time.perf_counter() - t0)
+        st = status.cpu().numpy()
+        pose = state.cpu()
+        if int(st[0]) != 1:
+            raise SystemExit("rank %d: alignment lost: result invalid" % rank)
+        if world > 1:      # every rank must hold the same bits
+            ref = pose.clone().to(env["coll_dev"])
+            dist.broadcast(ref, 0)
+            if not torch.equal(ref.cpu(), pose):
+                raise SystemExit("rank %d: pose differs from rank 0's: result invalid" % rank)
+        li = int(st[2])
+        level_iters = [li & 255, (li >> 8) & 255, (li >> 16) & 255]
+        # roofline of this rank's band kernel: 80 B per sampled model pixel of the band per executed iteration
+        lib = pkg.load()
+        tot_ms, launches = _profile(lib, ctx._h, "k_icp_iter", lambda: ([step() for _ in range(min(args.steps, 20))], stream.synchronize()))
+        reps = min(args.steps, 20)
+        band_bytes = 0
+        for lvl, it in enumerate(level_iters):
+            rows = (n // (1 << lvl) + 7) // 8 if (n // (1 << lvl)) % 8 else (n // (1 << lvl)) // 8
+            lo, hi = multigpu.band_rows(rank, world, rows)
+            band_bytes += 80 * min(8 * (hi - lo), n // (1 << lvl)) * (m // (1 << lvl)) * it
+        ev_ms = C.c_double()
+        lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev_ms))
+        # k_icp_iter launches that follow convergence exit at once; the event pairs cover them all
+        net_ms = max(1e-9, tot_ms - launches * ev_ms.value) if aligner.exchange != "fused" else tot_ms
+        achieved = band_bytes * reps / (net_ms * 1e-3) / 1e9
+        _barrier(env)
+        ctx.close()
+        if rank != 0:
+            return None
+        return {"metric": "row-sharded ICP alignments/sec at %dx%d" % (m, n), "value": round(args.steps / dt, 2), "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[3]: synthetic %dx%d pair (1 mm depth noise), 3-level Gauss-Newton ICP row-sharded into %d "
+                                       "bands of 8x8-block rows, 27-float exchange per iteration (%s), identical solve on every rank"
+                                       % (m, n, world, aligner.exchange),
+                           "icp_iterations_per_level": level_iters, "backend": env["backend"], "frames_resident_in_hbm": True},
+                "roofline": {"bound": "hbm", "kernel": "k_icp_iter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                             "algorithmic_bytes_per_frame": band_bytes, "launches_per_frame": round(launches / reps, 1),
+                             "note": "rank 0's band, all its k_icp_iter launches of a frame (incl. the no-op launches after convergence)"},
+                "cpu_baseline": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--mode", default="sequences", choices=["sequences", "planes", "rows"],
+                    help="sequences (default): the BASELINE metric, configs[1] at N=1 / configs[4] at N>1 (one sequence per GPU); "
+                         "planes: configs[2], 256 planes x 512x512, rank 0 tracks + broadcasts the frame, every rank fuses + decodes "
+                         "its planes; rows: configs[3], row-sharded ICP at 1920x1080 with the 27-float exchange")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer"],
+                    help="rows mode: how the 27 partial sums travel (torch.distributed all-gather, or peer-mapped slots)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--kernel", default="k_icp_iter", help="kernel whose roofline is reported")
@@ -209,6 +451,15 @@ def main():
 
     pkg = importlib.import_module("rgb-d-slam_amd")
     synth = importlib.import_module("rgb-d-slam_amd.synth")
+    if args.mode != "sequences":
+        env = {"torch": torch, "dist": dist, "rank": rank, "world": world, "local": local, "coll_dev": coll_dev, "pkg": pkg, "synth": synth,
+               "backend": backend}
+        out = run_planes(args, env) if args.mode == "planes" else run_rows(args, env)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     n, m = args.rows, args.cols
     calib = synth.calib_for(n, m)
     pool = synth.sequence(POOL_FRAMES, n, m, calib, noise_sigma=0.001, seed=rank)

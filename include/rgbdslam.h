@@ -405,6 +405,25 @@ int rgbdslam_detect_regions(rgbdslam_ctx *ctx, const float *NMap, const float *V
                             double canny_low, double canny_high, float thresh_discont, uint8_t thresh_edge,
                             int32_t *blob, int32_t *sizes, int32_t *work_labels, uint8_t *work_bytes, int n, int m);
 
+/* ---- 16-bit labels: models of more than 255 planes (BASELINE configs[2], 256 planes).  No reference counterpart: the
+ * reference's label image is u8 (Frame.h:197; label 0 = none, L = plane L-1, Primitive.cu:279-281), which caps a model at 255
+ * planes.  rgbdslam_update / rgbdslam_update_from_history with a u16 label image; same kernels, same winner rule. */
+int rgbdslam_update_l16(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                        uint64_t **ClaimTab, uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                        const uint16_t *Label16, const float *pose16_host, int N_prim, int M_prim, int n, int m, int plane_lo,
+                        int plane_hi);
+int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
+                                     uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, const float *VMap,
+                                     const float *RGBD, const uint8_t *Mask, const uint16_t *Label16, int N_prim, int M_prim,
+                                     int n, int m, int plane_lo, int plane_hi);
+/* Test / bench harness stand-in for plane detection on TILED models (like rgbdslam_seed_labels, not in the reference): a
+ * pixel takes the first plane k in [0, nb_planes) whose equation it satisfies (|n.p - d| <= epsilon, n.n_p >= alpha) and whose
+ * N_prim x M_prim Bump image contains its cell.  Pose: pose16_host (HOST pointer) or, when that is NULL, the device-resident
+ * history entry poseR(9, column-major) poset(3) ... written by rgbdslam_track_frame. */
+int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float *VMap, const float *NMap,
+                              const float *pose16_host, const float *history_entry_dev, float **ParamTab, int nb_planes,
+                              int N_prim, int M_prim, float epsilon, float alpha, int n, int m);
+
 /* ---- the rest of the reference's operator headers: everything else its unchanged host code calls ---------------------
  * (so that integration/rgbdslam_shim.cpp defines every symbol Frame.cpp / Graph.cpp / RG.cpp reference) */
 /* Kernel.cuh:22  void MergeDepthKinect(float *RGB_predicted, unsigned short *depth, float *RGB, unsigned char *mask, int n, int m)

@@ -497,3 +497,24 @@ def overlap(bump, mask, param, param_in, N_prim, M_prim):
     r = lib().orc_overlap(_p(np.ascontiguousarray(bump, np.uint16)), _p(np.ascontiguousarray(mask, np.uint8)), _p(_f32(param)),
                           _p(_f32(param_in)), n, m, N_prim, M_prim, _p(cnt))
     return float(r), cnt
+
+
+# ---- 16-bit labels (models of more than 255 planes) ------------------------------------------------------
+def update_l16(bumps, rgbs, masks, params, claims, stamp, vmap, rgbd, mask, label16, pose, plane_lo=0, plane_hi=None, size=None):
+    """In-place on the lists of per-plane numpy arrays (size = (N_prim, M_prim) when masks[0] is only a stand-in)."""
+    n, m, _ = vmap.shape
+    N_prim, M_prim = size if size is not None else masks[0].shape
+    if plane_hi is None:
+        plane_hi = len(masks)
+    lib().orc_update_l16(_ptr_table(bumps), _ptr_table(rgbs), _ptr_table(masks), _ptr_table(params), _ptr_table(claims),
+                         C.c_uint32(stamp), _p(_f32(vmap)), _p(_f32(rgbd)), _p(np.ascontiguousarray(mask, np.uint8)),
+                         _p(np.ascontiguousarray(label16, np.uint16)), _p(_f32(pose)), N_prim, M_prim, n, m, plane_lo, plane_hi)
+
+
+def label_planes_l16(vmap, nmap, pose, params, N_prim, M_prim, eps=0.1, alpha=0.8):
+    n, m, _ = vmap.shape
+    out = np.empty((n, m), np.uint16)
+    params = [_f32(p) for p in params]
+    lib().orc_label_planes_l16(_p(out), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _ptr_table(params), len(params),
+                               N_prim, M_prim, C.c_float(eps), C.c_float(alpha), n, m)
+    return out

@@ -659,10 +659,10 @@ static uint64_t claim_key(uint32_t stamp, int writer, uint8_t mask_curr, size_t 
 }
 
 /* geometry part of D1/Primitive.cu:278-307; returns 0 when the pixel takes no part */
-static int update_cell(const float *VMap, const uint8_t *Label, const float *pose, float **ParamTab,
+static int update_cell(const float *VMap, const uint8_t *Label, const uint16_t *Label16, const float *pose, float **ParamTab,
                        size_t idx, int N_prim, int M_prim, int plane_lo, int plane_hi,
                        int *lbl, int *cell, float *pa, float *pb, float *err) {
-    int L = (int)Label[idx] - 1;
+    int L = (Label16 ? (int)Label16[idx] : (int)Label[idx]) - 1;
     if (L < 0) return 0;
     if (L < plane_lo || L >= plane_hi) return 0;
     const float *P = ParamTab[L];
@@ -681,9 +681,9 @@ static int update_cell(const float *VMap, const uint8_t *Label, const float *pos
     return 1;
 }
 
-void orc_update(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+static void update_impl(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
                 uint64_t **ClaimTab, uint32_t stamp,
-                const float *VMap, const float *RGBD, const uint8_t *Mask, const uint8_t *Label,
+                const float *VMap, const float *RGBD, const uint8_t *Mask, const uint8_t *Label, const uint16_t *Label16,
                 const float *pose, int N_prim, int M_prim, int n, int m,
                 int plane_lo, int plane_hi) {
     size_t P = (size_t)n * m;
@@ -691,7 +691,7 @@ void orc_update(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float *
     #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < P; idx++) {
         int L, cell; float sa, sb, err;
-        if (!update_cell(VMap, Label, pose, ParamTab, idx, N_prim, M_prim, plane_lo, plane_hi, &L, &cell, &sa, &sb, &err)) continue;
+        if (!update_cell(VMap, Label, Label16, pose, ParamTab, idx, N_prim, M_prim, plane_lo, plane_hi, &L, &cell, &sa, &sb, &err)) continue;
         uint8_t mc = Mask[idx], mref = MaskTab[L][cell];
         uint64_t key;
         if (mc < 10 && mref != 1) key = claim_key(stamp, 0, 0, idx);            /* eroder, Primitive.cu:313 */
@@ -703,7 +703,7 @@ void orc_update(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float *
     #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < P; idx++) {
         int L, cell; float sa, sb, err;
-        if (!update_cell(VMap, Label, pose, ParamTab, idx, N_prim, M_prim, plane_lo, plane_hi, &L, &cell, &sa, &sb, &err)) continue;
+        if (!update_cell(VMap, Label, Label16, pose, ParamTab, idx, N_prim, M_prim, plane_lo, plane_hi, &L, &cell, &sa, &sb, &err)) continue;
         uint8_t mc = Mask[idx], mref = MaskTab[L][cell];
         uint64_t key;
         int erode = (mc < 10 && mref != 1);
@@ -726,6 +726,55 @@ void orc_update(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float *
             RGBTab[L][3 * cell + 1] = (uint8_t)f2i_rn((float)((double)RGBD[4 * idx + 1] * 255.0));
             RGBTab[L][3 * cell + 2] = (uint8_t)f2i_rn((float)((double)RGBD[4 * idx + 2] * 255.0));
             MaskTab[L][cell] = mc;
+        }
+    }
+}
+
+void orc_update(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                uint64_t **ClaimTab, uint32_t stamp,
+                const float *VMap, const float *RGBD, const uint8_t *Mask, const uint8_t *Label,
+                const float *pose, int N_prim, int M_prim, int n, int m,
+                int plane_lo, int plane_hi) {
+    update_impl(BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label, NULL, pose, N_prim, M_prim, n, m, plane_lo, plane_hi);
+}
+/* the same with 16-bit labels (models of more than 255 planes; no reference counterpart: Frame.h:197 keeps u8 labels) */
+void orc_update_l16(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                    uint64_t **ClaimTab, uint32_t stamp,
+                    const float *VMap, const float *RGBD, const uint8_t *Mask, const uint16_t *Label16,
+                    const float *pose, int N_prim, int M_prim, int n, int m,
+                    int plane_lo, int plane_hi) {
+    update_impl(BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, NULL, Label16, pose, N_prim, M_prim, n, m, plane_lo, plane_hi);
+}
+
+/* harness stand-in for plane detection on tiled models: first plane whose equation the pixel satisfies AND whose Bump
+ * image contains its cell (geometry of Primitive.cu:293-307) */
+void orc_label_planes_l16(uint16_t *Label16, const float *VMap, const float *NMap, const float *pose, float **ParamTab,
+                          int nb, int N_prim, int M_prim, float epsilon, float alpha, int n, int m) {
+    #pragma omp parallel for schedule(static)
+    for (size_t idx = 0; idx < (size_t)n * m; idx++) {
+        Label16[idx] = 0;
+        float n0 = NMap[3 * idx], n1 = NMap[3 * idx + 1], n2 = NMap[3 * idx + 2];
+        if (n0 == 0.0f && n1 == 0.0f && n2 == 0.0f) continue;
+        float l0 = VMap[3 * idx], l1 = VMap[3 * idx + 1], l2 = VMap[3 * idx + 2];
+        float p0 = ((pose[0] * l0 + pose[4] * l1) + pose[8] * l2) + pose[12];
+        float p1 = ((pose[1] * l0 + pose[5] * l1) + pose[9] * l2) + pose[13];
+        float p2 = ((pose[2] * l0 + pose[6] * l1) + pose[10] * l2) + pose[14];
+        float q0 = (pose[0] * n0 + pose[4] * n1) + pose[8] * n2;
+        float q1 = (pose[1] * n0 + pose[5] * n1) + pose[9] * n2;
+        float q2 = (pose[2] * n0 + pose[6] * n1) + pose[10] * n2;
+        for (int k = 0; k < nb; k++) {
+            const float *P = ParamTab[k];
+            float ea = (q0 * P[0] + q1 * P[1]) + q2 * P[2];
+            float err = ((p0 * P[0] + p1 * P[1]) + p2 * P[2]) - P[3];
+            float a = (p0 * P[8] + p1 * P[9]) + p2 * P[10];
+            float b = (p0 * P[11] + p1 * P[12]) + p2 * P[13];
+            a = (float)((double)((a - P[6]) * P[4]) / 2.0);
+            b = (float)((double)((b - P[7]) * P[5]) / 2.0);
+            int ii = f2i_rd(a), jj = f2i_rd(b);
+            int inside = !(ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0);
+            if (fabsf(err) > epsilon || ea < alpha || !inside) continue;
+            Label16[idx] = (uint16_t)(k + 1);
+            break;
         }
     }
 }

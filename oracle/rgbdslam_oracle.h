@@ -194,4 +194,12 @@ void orc_affect_plan(uint8_t *Label, const int32_t *Buff, int n, int m);
 float orc_overlap(const uint16_t *Bump, const uint8_t *Mask, const float *param, const float *param_in, int n, int m, int N_prim,
                   int M_prim, uint32_t *counter2);
 
+/* 16-bit labels (models of more than 255 planes) and the tiled-model labelling stand-in; checkers of
+ * rgbdslam_update_l16 / rgbdslam_label_planes_l16 */
+void orc_update_l16(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp,
+                    const float *VMap, const float *RGBD, const uint8_t *Mask, const uint16_t *Label16, const float *pose,
+                    int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi);
+void orc_label_planes_l16(uint16_t *Label16, const float *VMap, const float *NMap, const float *pose, float **ParamTab, int nb,
+                          int N_prim, int M_prim, float epsilon, float alpha, int n, int m);
+
 #endif

@@ -229,6 +229,25 @@ class Context:
     def raster_clear(self, zbuf, n, m):
         _chk(self.lib.rgbdslam_raster_clear(self._h, _ptr(zbuf), n, m), "raster_clear")
 
+    # -- 16-bit labels (models of more than 255 planes) --
+    def update_l16(self, bump_tab, rgb_tab, mask_tab, param_tab, claim_tab, stamp, vmap, rgbd, mask, label16, pose, N_prim,
+                   M_prim, n, m, plane_lo=0, plane_hi=0x7FFFFFFF):
+        _chk(self.lib.rgbdslam_update_l16(self._h, _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab), _ptr(param_tab), _ptr(claim_tab),
+                                          C.c_uint32(stamp), _ptr(vmap), _ptr(rgbd), _ptr(mask), _ptr(label16), _host16(pose),
+                                          N_prim, M_prim, n, m, plane_lo, plane_hi), "update_l16")
+
+    def update_from_history_l16(self, hist, bump_tab, rgb_tab, mask_tab, param_tab, claim_tab, stamp, vmap, rgbd, mask, label16,
+                                N_prim, M_prim, n, m, plane_lo=0, plane_hi=0x7FFFFFFF):
+        _chk(self.lib.rgbdslam_update_from_history_l16(self._h, _ptr(hist), _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab),
+                                                       _ptr(param_tab), _ptr(claim_tab), C.c_uint32(stamp), _ptr(vmap), _ptr(rgbd),
+                                                       _ptr(mask), _ptr(label16), N_prim, M_prim, n, m, plane_lo, plane_hi),
+             "update_from_history_l16")
+
+    def label_planes_l16(self, label16, vmap, nmap, pose, hist, param_tab, nb, N_prim, M_prim, n, m, eps=0.1, alpha=0.8):
+        _chk(self.lib.rgbdslam_label_planes_l16(self._h, _ptr(label16), _ptr(vmap), _ptr(nmap),
+                                                _host16(pose) if pose is not None else None, _ptr(hist), _ptr(param_tab), nb,
+                                                N_prim, M_prim, C.c_float(eps), C.c_float(alpha), n, m), "label_planes_l16")
+
     # -- the remaining operator functions of the reference headers (csrc/compat.hip) --
     def merge_depth_kinect(self, rgbd, depth, rgb, mask, n, m):
         _chk(self.lib.rgbdslam_merge_depth_kinect(self._h, _ptr(rgbd), _ptr(depth), _ptr(rgb), _ptr(mask), n, m), "merge_depth_kinect")
@@ -451,6 +470,14 @@ class RG:
 
     def synchronize(self):
         _hchk(self.lib.slamhost_rg_synchronize(self._h), "synchronize")
+
+    def frames_done(self):
+        return self.lib.slamhost_rg_frames_done(self._h)
+
+    def export_frame(self, dst, off_vmap, off_rgbd, off_mask, off_hist):
+        """Packs the merged model VMap / RGBD / Mask and the frame's history entry into `dst` (stream-ordered)."""
+        _hchk(self.lib.slamhost_rg_export_frame(self._h, _ptr(dst), C.c_size_t(off_vmap), C.c_size_t(off_rgbd), C.c_size_t(off_mask),
+                                                C.c_size_t(off_hist)), "export_frame")
 
     def pose(self):
         R = (C.c_float * 9)()

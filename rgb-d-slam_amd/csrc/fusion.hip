@@ -11,6 +11,7 @@ struct UpdateArgs {
     unsigned long long *const *ClaimTab;
     uint32_t stamp;
     const float *VMap, *RGBD; const uint8_t *Mask, *Label;
+    const uint16_t *Label16;                          // non-null: 16-bit labels (models of more than 255 planes), Label unused
     PoseV P;
     const rgbdslam_pose_block *pb;
     const float *hist;
@@ -25,6 +26,7 @@ __device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, c
     const uint32_t stamp = a.stamp;
     const float *__restrict__ VMap = a.VMap, *__restrict__ RGBD = a.RGBD;
     const uint8_t *__restrict__ Mask = a.Mask, *__restrict__ Label = a.Label;
+    const uint16_t *__restrict__ Label16 = a.Label16;
     PoseV P = a.P;
     const rgbdslam_pose_block *__restrict__ pb = a.pb;
     const float *__restrict__ hist = a.hist;
@@ -44,7 +46,7 @@ __device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, c
     int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
     const bool in = i < n && j < m;
     const size_t idx = in ? (size_t)i * m + j : 0;
-    int L = in ? (int)Label[idx] - 1 : -1;
+    int L = in ? (Label16 ? (int)Label16[idx] : (int)Label[idx]) - 1 : -1;
     const bool valid = L >= 0 && L >= plane_lo && L < plane_hi;
     const unsigned long long vmask = __ballot(valid);
     if (!vmask) return;
@@ -248,14 +250,14 @@ void k_vertex_from_bump_batch(float *const *__restrict__ VMapTab, float *const *
 static int launch_update(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, const float *hist, uint16_t **BumpTab, uint8_t **RGBTab,
                          uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, const float *VMap,
                          const float *RGBD, const uint8_t *Mask, const uint8_t *Label, const float *pose, int N_prim,
-                         int M_prim, int n, int m, int plane_lo, int plane_hi) {
-    if (!ctx || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !VMap || !RGBD || !Mask || !Label || (!pose && !pb && !hist))
+                         int M_prim, int n, int m, int plane_lo, int plane_hi, const uint16_t *Label16 = nullptr) {
+    if (!ctx || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !VMap || !RGBD || !Mask || (!Label && !Label16) || (!pose && !pb && !hist))
         return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;   // 23-bit pixel index in the claim key
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = pose ? pose[k] : 0.0f;
-    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, hist,
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, Label16, P, pb, hist,
                     N_prim, M_prim, n, m, plane_lo, plane_hi};
     KLAUNCH(ctx, k_update<false>, grid2d(n, m), block2d(), a);
     KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), a);
@@ -291,7 +293,7 @@ extern "C" int rgbdslam_update_apply_tracked(rgbdslam_ctx *ctx, const rgbdslam_p
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, nullptr,
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, P, pb, nullptr,
                     N_prim, M_prim, n, m, plane_lo, plane_hi};
     KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
@@ -315,7 +317,7 @@ extern "C" int rgbdslam_update_apply_tracked_preprocess(rgbdslam_ctx *ctx, const
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    UpdateArgs u = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, P, pb, nullptr,
+    UpdateArgs u = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, P, pb, nullptr,
                     N_prim, M_prim, n, m, plane_lo, plane_hi};
     PreprocessArgs p = {next_depth, depth_pitch, next_bgr, bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
     dim3 grid = grid2d(n, m);
@@ -334,6 +336,72 @@ extern "C" int rgbdslam_update_from_history(rgbdslam_ctx *ctx, const float *hist
     if (!history_entry_dev) return RGBDSLAM_E_ARG;
     return launch_update(ctx, nullptr, history_entry_dev, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, Label,
                          nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi);
+}
+
+// ---- 16-bit labels: models of more than 255 planes (BASELINE configs[2]: 256 planes; the reference's u8 label image,
+// Frame.h:197, caps a model at 255).  Same kernels, same winner rule; label 0 = none, L = plane L-1. ----------------------
+extern "C" int rgbdslam_update_l16(rgbdslam_ctx *ctx, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
+                                   uint64_t **ClaimTab, uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                                   const uint16_t *Label16, const float *pose, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                   int plane_hi) {
+    if (!pose || !Label16) return RGBDSLAM_E_ARG;
+    return launch_update(ctx, nullptr, nullptr, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, nullptr, pose, N_prim,
+                         M_prim, n, m, plane_lo, plane_hi, Label16);
+}
+extern "C" int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
+                                                uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp,
+                                                const float *VMap, const float *RGBD, const uint8_t *Mask, const uint16_t *Label16,
+                                                int N_prim, int M_prim, int n, int m, int plane_lo, int plane_hi) {
+    if (!history_entry_dev || !Label16) return RGBDSLAM_E_ARG;
+    return launch_update(ctx, nullptr, history_entry_dev, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, nullptr,
+                         nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi, Label16);
+}
+
+// Labels by plane membership for tiled models (test / bench harness stand-in for plane detection, like rgbdslam_seed_labels):
+// a pixel takes the FIRST plane k in [0, nb) whose equation it satisfies (|n.p - d| <= epsilon, n.n_p >= alpha) AND whose
+// N_prim x M_prim Bump image contains its cell -- so patches that tile one infinite plane get distinct labels.
+__global__ void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *__restrict__ VMap, const float *__restrict__ NMap,
+                                   PoseV P, const float *__restrict__ hist, const float *const *__restrict__ ParamTab, int nb, int N_prim,
+                                   int M_prim, float epsilon, float alpha, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    if (hist) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            P.v[4 * c] = hist[3 * c]; P.v[4 * c + 1] = hist[3 * c + 1]; P.v[4 * c + 2] = hist[3 * c + 2]; P.v[4 * c + 3] = 0.0f;
+        }
+        P.v[12] = hist[9]; P.v[13] = hist[10]; P.v[14] = hist[11]; P.v[15] = 1.0f;
+    }
+    size_t idx = (size_t)i * m + j;
+    uint16_t res = 0;
+    F3 nl = ld3(NMap, idx);
+    if (!is_zero3(nl)) {
+        const F3 p = xf_point(P.v, ld3(VMap, idx));
+        const F3 q = xf_dir(P.v, nl);
+        for (int k = 0; k < nb; k++) {                  // plane parameters through wave-uniform addresses
+            const float *Q = ParamTab[k];
+            float ea = (q.x * Q[0] + q.y * Q[1]) + q.z * Q[2];
+            UpdCell u;
+            const bool inside = update_cell(p, Q, N_prim, M_prim, u);
+            if (__builtin_fabsf(u.err) > epsilon || ea < alpha || !inside) continue;
+            res = (uint16_t)(k + 1);
+            break;
+        }
+    }
+    Label16[idx] = res;
+}
+extern "C" int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float *VMap, const float *NMap,
+                                         const float *pose16_host, const float *history_entry_dev, float **ParamTab, int nb_planes,
+                                         int N_prim, int M_prim, float epsilon, float alpha, int n, int m) {
+    if (!ctx || !Label16 || !VMap || !NMap || (!pose16_host && !history_entry_dev) || !ParamTab || n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0)
+        return RGBDSLAM_E_ARG;
+    if (nb_planes <= 0 || nb_planes > 65535) return RGBDSLAM_E_LIMIT;
+    PoseV P;
+    for (int k = 0; k < 16; k++) P.v[k] = pose16_host ? pose16_host[k] : 0.0f;
+    KLAUNCH(ctx, k_label_planes_l16, grid2d(n, m), block2d(), Label16, VMap, NMap, P, pose16_host ? nullptr : history_entry_dev,
+            (const float *const *)ParamTab, nb_planes, N_prim, M_prim, epsilon, alpha, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *RGBA, float *MaskOut, const uint16_t *Bump,

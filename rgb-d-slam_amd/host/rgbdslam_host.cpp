@@ -1013,6 +1013,18 @@ int RG::Sync() {
     return _pb_host->status[0];
 }
 
+void RG::ExportFrame(void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off_mask, size_t off_hist) {
+    if (!dst_dev || frames_done == 0) throw Error("ExportFrame: no frame processed yet", RGBDSLAM_E_STATE);
+    hipStream_t s = ctx_stream(_ctx);
+    const size_t P = (size_t)_predicted_frame->_n * _predicted_frame->_m;
+    char *d = (char *)dst_dev;
+    hip_check(hipMemcpyAsync(d + off_vmap, _predicted_frame->getVMap(), 12 * P, hipMemcpyDeviceToDevice, s), "export VMap");
+    hip_check(hipMemcpyAsync(d + off_rgbd, _predicted_frame->getRGB(), 16 * P, hipMemcpyDeviceToDevice, s), "export RGBD");
+    hip_check(hipMemcpyAsync(d + off_mask, _predicted_frame->_Mask_dev, P, hipMemcpyDeviceToDevice, s), "export Mask");
+    hip_check(hipMemcpyAsync(d + off_hist, _history_dev.p + 16 * (size_t)((frames_done - 1) % HISTORY_CAP), 64, hipMemcpyDeviceToDevice, s),
+              "export history entry");
+}
+
 const float *RG::history_host(int frame_index) { return _history_host + 16 * (size_t)(frame_index % HISTORY_CAP); }
 
 int RG::Step() {
@@ -1418,6 +1430,12 @@ int slamhost_copy_to_host(void *dst_host, const void *src_dev, size_t bytes) {
     hipError_t e = hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost);
     return e == hipSuccess ? 0 : -(int)e;
 }
+int slamhost_rg_frames_done(void *rg) { return rg ? ((RG *)rg)->frames_done : -1; }
+int slamhost_rg_export_frame(void *rg, void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off_mask, size_t off_hist) {
+    if (!rg || !dst_dev) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->ExportFrame(dst_dev, off_vmap, off_rgbd, off_mask, off_hist));
+    return 0;
+}
 int slamhost_rg_last_iterations(void *rg) { return rg ? ((RG *)rg)->last_iterations : -1; }
 int slamhost_rg_last_level_iterations(void *rg) { return rg ? ((RG *)rg)->last_level_iterations : -1; }
 void *slamhost_rg_ctx(void *rg) { return rg ? (void *)((RG *)rg)->ctx() : nullptr; }
@@ -1436,6 +1454,7 @@ int slamhost_rg_buffer(void *rgp, const char *name, void **ptr, size_t *bytes) {
     else if (s == "RGBD") { *ptr = pf->getRGB(); *bytes = 16 * P; }
     else if (s == "Mask") { *ptr = pf->_Mask_dev; *bytes = P; }
     else if (s == "Label") { *ptr = pf->_Label_dev; *bytes = P; }
+    else if (s == "history") { *ptr = rg->history_dev(); *bytes = 64 * (size_t)RG::HISTORY_CAP; }
     else if (s == "frame.VMap") { *ptr = rg->_frame->getVMap(); *bytes = 12 * P; }
     else if (s == "frame.NMap") { *ptr = rg->_frame->getNMap(); *bytes = 12 * P; }
     else if (s == "frame.RGB") { *ptr = rg->_frame->getRGB(); *bytes = 12 * P; }

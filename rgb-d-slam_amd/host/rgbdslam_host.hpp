@@ -273,6 +273,11 @@ public:
     int frames_done = 0;
     long tracked_total = 0;                                        // frames tracked so far (as of the last Sync)
     const float *history_host(int frame_index);                    // valid after Sync(); frame_index in the last HISTORY_CAP
+    float *history_dev() { return _history_dev.p; }                // the device ring itself (HISTORY_CAP entries of 16 floats)
+    // Plane-partitioned multi-GPU: copies what the plane owners need of the frame just enqueued -- the merged
+    // model VMap, RGBD, Mask and the frame's history entry (pose + tracked flag) -- into one packed device buffer at the
+    // given byte offsets, stream-ordered after the frame's kernels; the caller broadcasts that buffer.
+    void ExportFrame(void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off_mask, size_t off_hist);
 
     OffLineFrame *_frame;
     PredictedFrame *_predicted_frame;

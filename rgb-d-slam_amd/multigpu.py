@@ -73,8 +73,9 @@ class ShardedAligner:
     asynchronous -- no host sync between iterations.
     """
 
-    def __init__(self, ctx, prm, n, m, rank=None, world=None):
+    def __init__(self, ctx, prm, n, m, rank=None, world=None, exchange="allgather"):
         self.ctx, self.prm, self.n, self.m = ctx, prm, n, m
+        self.exchange = exchange
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.sums = torch.zeros(27, dtype=torch.float32, device="cuda")
@@ -113,3 +114,90 @@ class ShardedAligner:
         rc = lib.rgbdslam_align_end(h, p(pose_state), p(status))
         if rc:
             raise RuntimeError("align_end failed: %d" % rc)
+
+
+# ---- plane-partitioned fusion + decode (BASELINE configs[2]) -----------------------------------------------------------
+class FramePack:
+    """What the plane owners need of one tracked frame, as ONE contiguous buffer so that the step's only collective is one
+    broadcast: merged model VMap (f32x3), RGBD (f32x4), the frame's history entry (poseR(9) poset(3) tracked ...: pose +
+    gate), Mask (u8) and the 16-bit label image.  30 B/px + 64 B = 9.2 MB at 640x480."""
+
+    def __init__(self, n, m, device="cuda"):
+        P = n * m
+        up = lambda x: (x + 255) // 256 * 256
+        self.n, self.m = n, m
+        self.off_vmap = 0
+        self.off_rgbd = up(12 * P)
+        self.off_hist = up(self.off_rgbd + 16 * P)
+        self.off_mask = self.off_hist + 256
+        self.off_label = up(self.off_mask + P)
+        self.nbytes = up(self.off_label + 2 * P)
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+
+    def ptr(self, off):
+        return self.buf.data_ptr() + off
+
+    def view(self, name):
+        P = self.n * self.m
+        if name == "vmap":
+            return self.buf[self.off_vmap:self.off_vmap + 12 * P].view(torch.float32).view(self.n, self.m, 3)
+        if name == "rgbd":
+            return self.buf[self.off_rgbd:self.off_rgbd + 16 * P].view(torch.float32).view(self.n, self.m, 4)
+        if name == "hist":
+            return self.buf[self.off_hist:self.off_hist + 64].view(torch.float32)
+        if name == "mask":
+            return self.buf[self.off_mask:self.off_mask + P].view(self.n, self.m)
+        if name == "label":
+            return self.buf[self.off_label:self.off_label + 2 * P].view(torch.int16).view(self.n, self.m)
+        raise KeyError(name)
+
+    def broadcast(self, src=0):
+        """The one collective of the plane-partitioned step (RCCL broadcast over xGMI; gloo in the CPU tests)."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.buf.is_cuda and dist.get_backend() == "gloo":    # CPU rehearsal of N ranks on one card: staged through the host
+                host = self.buf.cpu()
+                dist.broadcast(host, src)
+                self.buf.copy_(host)
+            else:
+                dist.broadcast(self.buf, src)
+
+
+class PlaneShard:
+    """The planes [lo, hi) of a model of `nb` Bump images that this rank owns: their slabs, claim words and decode
+    outputs live here and nowhere else (the table entries of the other planes stay null; the kernels never touch a
+    plane outside [plane_lo, plane_hi))."""
+
+    def __init__(self, ctx, params, N, rank, world):
+        self.ctx, self.N = ctx, N
+        self.nb = int(params.shape[0])
+        self.lo, self.hi = plane_range(rank, world, self.nb)
+        k = self.hi - self.lo
+        self.param = torch.as_tensor(params, dtype=torch.float32).cuda().contiguous()   # every rank holds all equations (labels)
+        self.bump = torch.zeros(k, N, N, 3, dtype=torch.int16, device="cuda")
+        self.rgb = torch.zeros(k, N, N, 3, dtype=torch.uint8, device="cuda")
+        self.mask = torch.full((k, N, N), 10, dtype=torch.uint8, device="cuda")
+        self.claim = torch.zeros(k, N, N, dtype=torch.int64, device="cuda")
+        self.vout = torch.zeros(k, N, N, 3, device="cuda")
+        self.cout = torch.zeros(k, N, N, 4, device="cuda")
+        self.kout = torch.zeros(k, N, N, 4, device="cuda")
+        tab = lambda t: torch.tensor([0] * self.lo + [t[i].data_ptr() for i in range(k)] + [0] * (self.nb - self.hi),
+                                     dtype=torch.int64, device="cuda")
+        self.t_bump, self.t_rgb, self.t_mask, self.t_claim = tab(self.bump), tab(self.rgb), tab(self.mask), tab(self.claim)
+        self.t_vout, self.t_cout, self.t_kout = tab(self.vout), tab(self.cout), tab(self.kout)
+        self.t_param = torch.tensor([self.param[i].data_ptr() for i in range(self.nb)], dtype=torch.int64, device="cuda")
+        self.stamp = 0
+
+    def label(self, pack, vmap_ptr, nmap_ptr, eps=0.1, alpha=0.8):
+        """Tracking rank only: 16-bit labels of the model frame by plane membership, posed by the pack's history entry."""
+        self.ctx.label_planes_l16(pack.ptr(pack.off_label), vmap_ptr, nmap_ptr, None, pack.ptr(pack.off_hist), self.t_param, self.nb,
+                                  self.N, self.N, pack.n, pack.m, eps, alpha)
+
+    def fuse_and_decode(self, pack):
+        """Graph::Update (claim + apply) of the owned planes from the broadcast frame, then VertexFromBump of the owned planes."""
+        self.stamp += 1
+        if self.hi > self.lo:
+            self.ctx.update_from_history_l16(pack.ptr(pack.off_hist), self.t_bump, self.t_rgb, self.t_mask, self.t_param, self.t_claim,
+                                             self.stamp, pack.ptr(pack.off_vmap), pack.ptr(pack.off_rgbd), pack.ptr(pack.off_mask),
+                                             pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m, self.lo, self.hi)
+            self.ctx.vertex_from_bump_batch(self.t_vout, self.t_cout, self.t_kout, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
+                                            self.lo, self.hi, self.N, self.N)

@@ -136,3 +136,30 @@ def sequence(n_frames, n=480, m=640, calib=None, noise_sigma=0.0, seed=0):
     for R, t in trajectory(n_frames, seed):
         out.append(render(R, t, n, m, calib, noise_sigma, rng))
     return out
+
+
+def tiled_planes(nb=256, N=512, res=0.004):
+    """BASELINE configs[2] "large planar scene": the three planes of the room corner, each tiled into square patches of
+    N x N Bump cells (N * res = 2.048 m at N = 512), nb patches in all (spread evenly over the three planes, each plane's
+    patches on a square grid centred on the plane's centre point, ordered from the rim inwards).  Returns the 14-float parameter blocks [nb, 14] in
+    the layout of Primitive::SetParam (D1/Primitive.h:180-190): n(3) d scale(2) shift(2) e1(3) e2(3), scale = 2 / res
+    (RG.cpp:706), shift = lower-left corner of the patch in plane coordinates (RG.cpp:720-721)."""
+    eq, centers = plane_equations()
+    params = np.zeros((nb, 14), np.float32)
+    side = np.float32(N * res)
+    k = 0
+    for p in range(3):
+        cnt = nb // 3 + (1 if p < nb % 3 else 0)
+        g = int(np.ceil(np.sqrt(cnt)))
+        E, c = eq[p], centers[p]
+        c0, c1 = np.float32(c @ E[3:6]), np.float32(c @ E[6:9])
+        # outermost patches first, the patch under the plane's centre last: the visible patches of the last plane then
+        # carry the highest labels (nb itself among them -- beyond the u8 range when nb > 255)
+        tiles = sorted(((t // g, t % g) for t in range(cnt)),
+                       key=lambda ab: -((ab[0] + 0.5 - g / 2.0) ** 2 + (ab[1] + 0.5 - g / 2.0) ** 2))
+        for a, b in tiles:
+            sh0 = np.float32(c0 + (a - g / 2.0) * side)
+            sh1 = np.float32(c1 + (b - g / 2.0) * side)
+            params[k] = [E[0], E[1], E[2], E[9], 2.0 / res, 2.0 / res, sh0, sh1, E[3], E[4], E[5], E[6], E[7], E[8]]
+            k += 1
+    return params
