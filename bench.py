@@ -281,6 +281,11 @@ def run_planes(args, env):
                 acc["fuse_decode"] += marks[q + 2][1].elapsed_time(marks[q + 3][1])
             phases = {k_: round(v / reps * 1e3, 1) for k_, v in acc.items()}
             phases["unit"] = "us per step on rank 0 (event pairs on its stream, second pass)"
+        # "a checksum of checksums": the model after all steps, independent of how the planes were partitioned
+        chk = torch.tensor([int(shard.bump.to(torch.int64).sum()) + 3 * int(shard.rgb.to(torch.int64).sum()) + 7 * int(shard.mask.to(torch.int64).sum()),
+                            int((shard.mask > 10).sum())], dtype=torch.int64, device=env["coll_dev"])
+        if world > 1:
+            dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         cells = (shard.hi - shard.lo) * N * N
         ev_ms = C.c_double()
         lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev_ms))
@@ -303,7 +308,8 @@ def run_planes(args, env):
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                             "algorithmic_bytes_per_launch": 54 * cells, "avg_launch_us": round(avg_ms * 1e3, 2),
                             "note": "rank 0's share: 54 B per owned Bump cell per launch"},
-               "phases": phases, "cpu_baseline": None}
+               "phases": phases, "cpu_baseline": None,
+               "model_checksum": int(chk[0].item()), "cells_fused": int(chk[1].item())}
         rg.close()
         ctx.close()
         return out
@@ -382,7 +388,7 @@ def run_rows(args, env):
         ev_ms = C.c_double()
         lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev_ms))
         # k_icp_iter launches that follow convergence exit at once; the event pairs cover them all
-        net_ms = max(1e-9, tot_ms - launches * ev_ms.value) if aligner.exchange != "fused" else tot_ms
+        net_ms = max(1e-9, tot_ms - launches * ev_ms.value)
         achieved = band_bytes * reps / (net_ms * 1e-3) / 1e9
         _barrier(env)
         ctx.close()
@@ -394,7 +400,8 @@ def run_rows(args, env):
                 "config": {"workload": "BASELINE configs[3]: synthetic %dx%d pair (1 mm depth noise), 3-level Gauss-Newton ICP row-sharded into %d "
                                        "bands of 8x8-block rows, 27-float exchange per iteration (%s), identical solve on every rank"
                                        % (m, n, world, aligner.exchange),
-                           "icp_iterations_per_level": level_iters, "backend": env["backend"], "frames_resident_in_hbm": True},
+                           "icp_iterations_per_level": level_iters, "backend": env["backend"], "frames_resident_in_hbm": True,
+                           "pose": [float(x) for x in pose[:12].tolist()]},
                 "roofline": {"bound": "hbm", "kernel": "k_icp_iter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                              "algorithmic_bytes_per_frame": band_bytes, "launches_per_frame": round(launches / reps, 1),

@@ -156,6 +156,23 @@ int rgbdslam_align_solve_gathered(rgbdslam_ctx *ctx, const rgbdslam_icp_params *
                                   int lvl, int iter, float *trace_dev);
 int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int32_t *status_dev);
 
+/* The same row-sharded iteration with the exchange INSIDE the launch (one launch per iteration per rank instead of three plus
+ * a host-driven collective): every rank's kernel writes its 27 band sums as one checksummed 128-byte line into its slot of
+ * every peer's exchange block (peer-mapped fine-grained device memory: xGMI stores, no RCCL call), waits until all ranks'
+ * lines of this iteration have arrived in its own block, adds them in rank order and runs the identical solve.
+ * Set-up: rgbdslam_exchange_create on every rank (returns an IPC handle), all-gather the handles by any means,
+ * rgbdslam_exchange_connect.  world <= 8; every rank must issue the same sequence of rgbdslam_align_band_exchange calls and own
+ * a non-empty band.  A rank that waits 50 ms in vain marks the frame lost and raises the fault count (rgbdslam_icp_loop_faults). */
+#define RGBDSLAM_EXCHANGE_HANDLE_BYTES 64
+int rgbdslam_exchange_create(rgbdslam_ctx *ctx, int world, int rank, void *handle_out);
+int rgbdslam_exchange_connect(rgbdslam_ctx *ctx, const void *all_handles);
+int rgbdslam_exchange_destroy(rgbdslam_ctx *ctx);
+int rgbdslam_align_band_exchange(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap, const float *NMap,
+                                 const float *RGB, const float *Gx, size_t gx_pitch, const float *Gy, size_t gy_pitch,
+                                 const float *VMap_prev, const float *NMap_prev, const float *RGB_prev, int n_row, int m_col,
+                                 int lvl, int iter, int block_row_lo, int block_row_hi, const float *pose_state_dev,
+                                 float *trace_dev);
+
 /* ---- fused frame pipeline ------------------------------------------------------------------
  * One entry point per METHOD of the reference's L3/L4 classes instead of one per operator; same
  * per-pixel arithmetic (results are bit-identical to the per-operator entry points).  The tracker

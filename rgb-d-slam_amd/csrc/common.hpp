@@ -49,6 +49,10 @@ struct rgbdslam_ctx {
     int prof_cap, prof_n;
     int prof_launches;     // launches covered by the recorded event pairs
     bool prof_in_group;    // inside prof_group_begin/end: launches are counted, the group carries the one event pair
+    // row-sharded ICP: peer-mapped exchange blocks (rgbdslam_exchange_*), slot r of every block = rank r's line of sums
+    unsigned int *xchg_peer[8];    // [xchg_rank] = this rank's own block; the others are IPC mappings of the peers' blocks
+    int xchg_world, xchg_rank;
+    unsigned int xchg_seq;         // advances once per exchanged iteration, in lockstep on every rank
     // compat.hip: work buffers behind the reference-shaped Update_cu / Segment_cu / Overlap_cu (allocated on first use)
     uint64_t *claim_slab[RGBDSLAM_COMPAT_MAX_PLANES];   // one u64 claim word per Bump cell and plane
     uint64_t **claim_tab_dev;                           // device copy of claim_slab

@@ -8,6 +8,7 @@
 // D1/ICP.cu:28-48), and the second stage repeats ReduceKernel's 512-strided chains + tree
 // (D1/ICP.cu:50-70): the 27 sums are bit-identical to a serial restatement of the reference.
 #include "common.hpp"
+#include <string.h>
 
 #define ICP_CHAIN_WAVES 5  // waves (= 8x8 blocks in flight) per chain: 640x480 has 9.4 blocks per chain -> two balanced rounds
 #define ICP_WG_CHAINS 2    // a workgroup owns chains t and t+256 and adds their sums itself (first level of reduce<512>):
@@ -186,7 +187,15 @@ __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
 // pairing of reduce<512> and runs the 6x6 solve -- so one launch replaces the reference's
 // memset + MatchKernel + memset + ReduceKernel + D2H + host solve + H2D (D1/ICP.cu:254-286,
 // RG.cpp:851-901) with bit-identical sums.
+// Row-sharded ICP across GPUs: every rank's tail publishes its band's 27 sums as one 128-byte line into slot
+// `rank` of EVERY peer's exchange block (peer-mapped, fine-grained device memory) and then waits until all `world` slots of
+// its own block carry this iteration's sequence.  Line = four 32-byte sectors of 7 payload words + 1 tag word, tag =
+// seq ^ xor(payload words of the sector): a sector is accepted only when tag ^ xor(payload) == seq, so neither a stale nor
+// a torn sector (whatever granularity the fabric writes at) can pass for this iteration's.
+#define ICP_XCHG_MAX_WORLD 8
+struct IcpXchg { unsigned int *peer[ICP_XCHG_MAX_WORLD]; int world, rank; unsigned int seq; };
 struct IcpIterArgs {
+    IcpXchg xchg;                                    // world == 0: no exchange
     const float *intr, *R, *t;                       // device scalars (user buffers or &IcpState fields)
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
     size_t gxp, gyp;
@@ -206,6 +215,7 @@ struct IcpIterArgs {
     float thr_alpha, thr_tr;
     float *trace;
     long long *timing;                               // optional debug: phase time stamps (wall_clock64, 10 ns ticks)
+    int *fault;                                      // optional: set to 1 when a wait gives up (rgbdslam_icp_loop_faults)
     // track_frame path: the first launch builds the loop state itself (k_icp_begin), the last one
     // appends the track-loss test, the commit and the display() pose algebra (k_icp_end)
     int first_launch, final_launch;
@@ -454,6 +464,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             if (wall_clock64() - t_poll > 5000000) {  // 50 ms: a workgroup of this step never ran (the device is not ours):
 #pragma unroll
                 for (int j = 0; j < 16; j++) r[j] = __builtin_nanf("");   // the solve rejects the system, the frame counts as lost
+                if (a.fault && lane == 0) __hip_atomic_store(a.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
@@ -475,6 +486,56 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     }
     long long ts4 = a.timing ? wall_clock64() : 0;
     __syncthreads();
+    if (!LOOP && a.xchg.world > 0) {                  // uniform over the grid; the tail is the only workgroup still here
+        if (wave == 0) {
+            // publish: slot l of the line = term l - l/8 (as in the chain lines), tag words in slots 7, 15, 23, 31
+            const int k = lane - (lane >> 3);
+            unsigned int word = ((lane & 7) != 7 && k < 27 && lane < 32) ? __float_as_uint(fin[k]) : 0u;
+            unsigned int x = word;
+            x ^= (unsigned int)__shfl_xor((int)x, 1); x ^= (unsigned int)__shfl_xor((int)x, 2); x ^= (unsigned int)__shfl_xor((int)x, 4);
+            if ((lane & 7) == 7) word = a.xchg.seq ^ x;
+            for (int p = 0; p < a.xchg.world; p++)
+                if (lane < 32)
+                    __hip_atomic_store(a.xchg.peer[p] + 32 * a.xchg.rank + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // gather: lane reads word lane % 32 of lines 2i + lane / 32 of the own block
+            const unsigned int *mine = a.xchg.peer[a.xchg.rank];
+            unsigned int v[ICP_XCHG_MAX_WORLD / 2];
+            const long long t_poll = wall_clock64();
+            bool gave_up = false;
+            for (;;) {
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < ICP_XCHG_MAX_WORLD / 2; i++) {
+                    const int line = 2 * i + (lane >> 5);
+                    const bool live = line < a.xchg.world;
+                    v[i] = live ? __hip_atomic_load(mine + 32 * line + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                    unsigned int y = v[i];
+                    y ^= (unsigned int)__shfl_xor((int)y, 1); y ^= (unsigned int)__shfl_xor((int)y, 2); y ^= (unsigned int)__shfl_xor((int)y, 4);
+                    bad |= live && y != a.xchg.seq;
+                }
+                if (__ballot(bad) == 0ull) break;
+                if (wall_clock64() - t_poll > 5000000) { gave_up = true; break; }   // 50 ms: a peer never published
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // rank-ordered total (the order of k_icp_solve), through this wave's LDS scratch
+            unsigned int *lds = (unsigned int *)tr[0];
+#pragma unroll
+            for (int i = 0; i < ICP_XCHG_MAX_WORLD / 2; i++) lds[32 * (2 * i + (lane >> 5)) + (lane & 31)] = v[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 27) {
+                const int slot = lane + lane / 7;
+                float tot = __uint_as_float(lds[slot]);
+                for (int p = 1; p < a.xchg.world; p++) tot = tot + __uint_as_float(lds[32 * p + slot]);
+                if (gave_up) tot = __builtin_nanf("");
+                fin[lane] = tot;
+                a.sums[lane] = tot;
+            }
+            if (gave_up && lane == 0 && a.fault) __hip_atomic_store(a.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     if (a.do_solve) {
         IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
         icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh,
@@ -559,6 +620,7 @@ void k_icp_loop(IcpLoopArgs L) {
         const int nchain = min(grid_rows * grid_cols, ICP_CHAINS);
         if (t < min(nchain, ICP_WGS)) {
             IcpIterArgs a;
+            a.xchg.world = 0; a.fault = (int *)(L.block + ICP_OFF_EPOCH + 128);
             a.intr = nullptr; a.R = nullptr; a.t = nullptr;
             a.VMap = L.VMap; a.NMap = L.NMap; a.RGB = L.RGB; a.Gx = L.Gx; a.Gy = L.Gy; a.gxp = L.gxp; a.gyp = L.gyp;
             a.VMap_prev = L.VMap_prev; a.NMap_prev = L.NMap_prev; a.RGBD_prev = L.RGBD_prev;
@@ -1056,7 +1118,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
                        float distThres, float angleThres, int n, int m, int fact, int br_lo, int br_hi, float *sums,
                        int32_t *corr, IcpState *state, const float *pose_state, int do_solve, int lvl, int iter, int max_iter,
                        float thr_alpha, float thr_tr, float *trace, int first_launch = 0, int final_launch = 0,
-                       const IcpEndArgs *end = nullptr) {
+                       const IcpEndArgs *end = nullptr, const IcpXchg *xchg = nullptr) {
     int gr = div_up(n / fact, 8), gc = div_up(m / fact, 8);   // D1/ICP.cu:260-261
     if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
     if (br_lo < 0) br_lo = 0;
@@ -1064,6 +1126,8 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     if (br_hi <= br_lo) return RGBDSLAM_E_ARG;
     if (!ctx->buf_dev) return RGBDSLAM_E_STATE;
     IcpIterArgs a;
+    if (xchg) a.xchg = *xchg; else a.xchg.world = 0;
+    a.fault = ctx->icp_epoch_dev ? (int *)(ctx->icp_epoch_dev + 32) : nullptr;
     a.intr = intr; a.R = R; a.t = t;
     a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
     a.VMap_prev = mp.VMap_prev; a.NMap_prev = mp.NMap_prev; a.RGBD_prev = mp.RGB_prev;
@@ -1251,4 +1315,92 @@ extern "C" int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int3
             (float *)nullptr, 0);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// ---- peer-mapped exchange of the 27 band sums (row-sharded ICP over several GPUs; no reference counterpart) ----------
+#define XCHG_BLOCK_BYTES (ICP_XCHG_MAX_WORLD * 128)
+static_assert(sizeof(hipIpcMemHandle_t) <= RGBDSLAM_EXCHANGE_HANDLE_BYTES, "IPC handle size");
+
+extern "C" int rgbdslam_exchange_create(rgbdslam_ctx *ctx, int world, int rank, void *handle_out) {
+    if (!ctx || world < 1 || world > ICP_XCHG_MAX_WORLD || rank < 0 || rank >= world) return RGBDSLAM_E_ARG;
+    if (ctx->xchg_world) return RGBDSLAM_E_STATE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // fine-grained device memory: stores arriving over xGMI and the local polls meet at the memory, not in a stale L2 line
+    void *blk = nullptr;
+    if (hipExtMallocWithFlags(&blk, XCHG_BLOCK_BYTES, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMalloc(&blk, XCHG_BLOCK_BYTES));
+    }
+    HIP_TRY(hipMemset(blk, 0, XCHG_BLOCK_BYTES));
+    if (handle_out) {
+        memset(handle_out, 0, RGBDSLAM_EXCHANGE_HANDLE_BYTES);
+        if (world > 1) {
+            hipIpcMemHandle_t h;
+            hipError_t e = hipIpcGetMemHandle(&h, blk);
+            if (e != hipSuccess) { (void)hipFree(blk); return -(int)e; }
+            memcpy(handle_out, &h, sizeof(h));
+        }
+    }
+    ctx->xchg_peer[rank] = (unsigned int *)blk;
+    ctx->xchg_world = world; ctx->xchg_rank = rank; ctx->xchg_seq = 0;
+    return 0;
+}
+
+// all_handles: world x RGBDSLAM_EXCHANGE_HANDLE_BYTES, entry r = what rank r's rgbdslam_exchange_create returned
+extern "C" int rgbdslam_exchange_connect(rgbdslam_ctx *ctx, const void *all_handles) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    if (!ctx->xchg_world) return RGBDSLAM_E_STATE;
+    if (ctx->xchg_world > 1 && !all_handles) return RGBDSLAM_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int r = 0; r < ctx->xchg_world; r++) {
+        if (r == ctx->xchg_rank || ctx->xchg_peer[r]) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)all_handles + (size_t)r * RGBDSLAM_EXCHANGE_HANDLE_BYTES, sizeof(h));
+        void *p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        ctx->xchg_peer[r] = (unsigned int *)p;
+    }
+    return 0;
+}
+
+extern "C" int rgbdslam_exchange_destroy(rgbdslam_ctx *ctx) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    if (!ctx->xchg_world) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int r = 0; r < ctx->xchg_world; r++) {
+        if (!ctx->xchg_peer[r]) continue;
+        if (r == ctx->xchg_rank) (void)hipFree(ctx->xchg_peer[r]);
+        else (void)hipIpcCloseMemHandle(ctx->xchg_peer[r]);
+        ctx->xchg_peer[r] = nullptr;
+    }
+    ctx->xchg_world = 0;
+    return 0;
+}
+
+// One Gauss-Newton iteration of the row-sharded loop in ONE launch per rank: band sums -> line into every peer's slot ->
+// wait for all ranks' lines -> rank-ordered total -> the identical solve.  Replaces align_band_system + all-gather +
+// align_solve_gathered (same arithmetic, same summation order: bit-identical poses).  Every rank must make the same
+// sequence of calls (the sequence word advances per call), and every rank's band must be non-empty.
+extern "C" int rgbdslam_align_band_exchange(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap, const float *NMap,
+                                            const float *RGB, const float *Gx, size_t gxp, const float *Gy, size_t gyp,
+                                            const float *VMap_prev, const float *NMap_prev, const float *RGB_prev, int n, int m,
+                                            int lvl, int iter, int block_row_lo, int block_row_hi, const float *pose_state_dev,
+                                            float *trace_dev) {
+    if (!ctx || !prm || !VMap || !NMap || !RGB || !Gx || !Gy || !VMap_prev || !NMap_prev || !RGB_prev || !pose_state_dev)
+        return RGBDSLAM_E_ARG;
+    int rc = check_align_args(ctx, prm, n, m, gxp, gyp);
+    if (rc) return rc;
+    if (lvl < 0 || lvl >= prm->lvl || iter < 0 || block_row_hi <= block_row_lo) return RGBDSLAM_E_ARG;
+    if (!ctx->xchg_world) return RGBDSLAM_E_STATE;
+    IcpXchg x;
+    for (int r = 0; r < ICP_XCHG_MAX_WORLD; r++) x.peer[r] = r < ctx->xchg_world ? ctx->xchg_peer[r] : nullptr;
+    for (int r = 0; r < ctx->xchg_world; r++)
+        if (!x.peer[r]) return RGBDSLAM_E_STATE;              // rgbdslam_exchange_connect has not run
+    x.world = ctx->xchg_world; x.rank = ctx->xchg_rank; x.seq = ++ctx->xchg_seq;
+    IcpState *st = ctx->icp_state;
+    IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
+    return launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, 1 << lvl, block_row_lo,
+                       block_row_hi, ctx->outbuf_dev, nullptr, st, pose_state_dev, 1, lvl, iter, prm->max_iter[lvl],
+                       prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev, 0, 0, nullptr, &x);
 }

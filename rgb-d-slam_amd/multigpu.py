@@ -80,6 +80,33 @@ class ShardedAligner:
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.sums = torch.zeros(27, dtype=torch.float32, device="cuda")
         self.gathered = torch.zeros(self.world, 27, dtype=torch.float32, device="cuda")
+        if exchange == "peer":
+            self._connect_peers()
+
+    HANDLE_BYTES = 64   # RGBDSLAM_EXCHANGE_HANDLE_BYTES
+
+    def _connect_peers(self):
+        """Peer-mapped exchange blocks: every rank exports an IPC handle of its block, the handles are all-gathered once
+        (through torch.distributed, whatever the backend), and every rank maps its peers' blocks.  After that the
+        per-iteration exchange is stores over xGMI from inside the iteration kernel -- no collective call, no host."""
+        lib, h = self.ctx.lib, self.ctx._h
+        mine = (C.c_ubyte * self.HANDLE_BYTES)()
+        rc = lib.rgbdslam_exchange_create(h, self.world, self.rank, mine)
+        if rc:
+            raise RuntimeError("exchange_create failed: %d" % rc)
+        everyone = (C.c_ubyte * (self.HANDLE_BYTES * self.world))()
+        if self.world > 1:
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+            out = torch.empty(self.world * self.HANDLE_BYTES, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(out, t)
+            for k, v in enumerate(out.cpu().tolist()):
+                everyone[k] = v
+        rc = lib.rgbdslam_exchange_connect(h, everyone)
+        if rc:
+            raise RuntimeError("exchange_connect failed: %d" % rc)
+        if self.world > 1:
+            dist.barrier()          # nobody starts publishing before every mapping exists
 
     @staticmethod
     def _div_up(x, y):
@@ -96,6 +123,15 @@ class ShardedAligner:
             grid_rows = self._div_up(n // (1 << lvl), 8)
             lo, hi = band_rows(self.rank, self.world, grid_rows)
             for it in range(prm.max_iter[lvl] + 2):
+                if self.exchange == "peer":
+                    if hi <= lo:
+                        raise RuntimeError("peer exchange needs a non-empty band on every rank (level %d has %d block rows)" % (lvl, grid_rows))
+                    rc = lib.rgbdslam_align_band_exchange(h, C.byref(prm), p(vmap), p(nmap), p(rgb), p(gx), C.c_size_t(pitch), p(gy),
+                                                          C.c_size_t(pitch), p(vprev), p(nprev), p(rgbd_prev), n, m, lvl, it, lo, hi,
+                                                          p(pose_state), None)
+                    if rc:
+                        raise RuntimeError("align_band_exchange failed: %d" % rc)
+                    continue
                 if hi > lo:
                     rc = lib.rgbdslam_align_band_system(h, C.byref(prm), p(vmap), p(nmap), p(rgb), p(gx), C.c_size_t(pitch), p(gy),
                                                         C.c_size_t(pitch), p(vprev), p(nprev), p(rgbd_prev), n, m, lvl, it, lo, hi,
@@ -106,6 +142,10 @@ class ShardedAligner:
                     self.sums.zero_()                       # more ranks than block rows: an empty band contributes zeros
                 if self.world == 1:
                     self.gathered[0].copy_(self.sums)
+                elif dist.get_backend() == "gloo":              # CPU rehearsal of N ranks on one card: staged through the host
+                    host = torch.empty(self.world * 27, dtype=torch.float32)
+                    dist.all_gather_into_tensor(host, self.sums.cpu())
+                    self.gathered.view(-1).copy_(host)
                 else:
                     dist.all_gather_into_tensor(self.gathered.view(-1), self.sums)
                 rc = lib.rgbdslam_align_solve_gathered(h, C.byref(prm), p(self.gathered), self.world, p(pose_state), lvl, it, None)

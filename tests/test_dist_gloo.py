@@ -155,3 +155,47 @@ def test_partitions_cover_everything():
         assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ---- plane-partitioned step with its one collective: the packed frame broadcast (16-bit labels, tiled model) ----------
+def _plane_step_broadcast(rank, world):
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m, N, nb = 60, 80, 64, 12
+    orc, synth, calib, s = _scene(n, m)
+    params = synth.tiled_planes(nb, N)
+    pose = np.eye(4, dtype=np.float32).T.reshape(-1)
+    pack = mg.FramePack(n, m, device="cpu")
+    hist = np.zeros(16, np.float32)
+    hist[:9] = np.eye(3, dtype=np.float32).reshape(-1); hist[12] = 1.0
+    label = orc.label_planes_l16(s["v0"], s["n0"], pose, list(params), N, N)
+    mask = orc.init_mask(s["rgbd0"])
+    if rank == 0:                                       # the tracking rank fills the pack; the others receive it
+        pack.view("vmap").copy_(torch.from_numpy(s["v0"]))
+        pack.view("rgbd").copy_(torch.from_numpy(s["rgbd0"]))
+        pack.view("hist").copy_(torch.from_numpy(hist))
+        pack.view("mask").copy_(torch.from_numpy(mask))
+        pack.view("label").copy_(torch.from_numpy(label.view(np.int16)))
+    pack.broadcast(0)
+    got = dict(v=pack.view("vmap").numpy(), rgbd=pack.view("rgbd").numpy(), mask=pack.view("mask").numpy(),
+               label=pack.view("label").numpy().view(np.uint16), hist=pack.view("hist").numpy())
+    same_frame = (np.array_equal(got["v"], s["v0"]) and np.array_equal(got["rgbd"], s["rgbd0"]) and np.array_equal(got["mask"], mask)
+                  and np.array_equal(got["label"], label) and np.array_equal(got["hist"], hist))
+    lo, hi = mg.plane_range(rank, world, nb)
+    mk = lambda shape, dt, v=0: [np.full(shape, v, dt) for _ in range(nb)]
+    mine = (mk((N, N, 3), np.uint16), mk((N, N, 3), np.uint8), mk((N, N), np.uint8, 10))
+    orc.update_l16(mine[0], mine[1], mine[2], list(params), mk((N, N), np.uint64), 1, got["v"], got["rgbd"], got["mask"], got["label"], pose, lo, hi)
+    ref = (mk((N, N, 3), np.uint16), mk((N, N, 3), np.uint8), mk((N, N), np.uint8, 10))
+    orc.update_l16(ref[0], ref[1], ref[2], list(params), mk((N, N), np.uint64), 1, s["v0"], s["rgbd0"], mask, label, pose)
+    owned_ok = all(np.array_equal(mine[c][k], ref[c][k]) for c in range(3) for k in range(lo, hi))
+    others_untouched = all((mine[2][k] == 10).all() for k in range(nb) if not lo <= k < hi)
+    return dict(same_frame=same_frame, owned_ok=owned_ok, others_untouched=others_untouched, range=(lo, hi),
+                labels=sorted(set(np.unique(label).tolist())), filled=int(sum((ref[2][k] > 10).sum() for k in range(nb))),
+                nbytes=pack.nbytes)
+
+
+def test_plane_partitioned_step_with_frame_broadcast_two_ranks():
+    out = _spawn(_plane_step_broadcast)
+    assert out[0]["range"] == (0, 6) and out[1]["range"] == (6, 12)
+    assert all(o["same_frame"] and o["owned_ok"] and o["others_untouched"] for o in out)
+    assert len(out[0]["labels"]) >= 4 and out[0]["filled"] > 300
+    assert out[0]["nbytes"] >= 30 * 60 * 80 + 64

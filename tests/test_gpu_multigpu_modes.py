@@ -1,0 +1,103 @@
+"""The runnable N-rank forms of BASELINE configs[2] / configs[3] (bench.py --mode planes | rows) on ONE card.
+
+* world size 1 through the real code paths (RCCL not needed for one rank): peer-slot exchange == all-gather path, bit for bit;
+* 2 ranks rehearsed on one GPU (gloo for the process group, RGBDSLAM_BENCH_DEVICE=0): the peer exchange maps each other's
+  block over HIP IPC and both ranks must hold identical poses (bench.py checks that itself and refuses otherwise); the
+  plane-partitioned model after N steps must carry the same checksum as the single-rank run.
+Never more than 2 ranks on the card."""
+import importlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(args, world=1, timeout=170):
+    env = dict(os.environ)
+    if world > 1:
+        env.update(RGBDSLAM_BENCH_BACKEND="gloo", RGBDSLAM_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_peer_exchange_equals_allgather_single_rank(pkg, synth, orc):
+    multigpu = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m = 240, 320
+    calib = synth.calib_for(n, m)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(2)
+    d0, c0 = synth.render(np.eye(3), np.zeros(3), n, m, calib, noise_sigma=0.001, rng=rng)
+    R1, t1 = synth.pair_offset_pose()
+    d1, c1 = synth.render(R1, t1, n, m, calib, noise_sigma=0.001, rng=rng)
+    v0 = orc.vertex_map_kinect(d0, calib); n0 = orc.compute_normal(v0); rgb0 = orc.cpy_char3(c0)
+    v1 = orc.vertex_map_kinect(d1, calib); n1 = orc.compute_normal(v1); rgb1 = orc.cpy_char3(c1)
+    rgbd0 = orc.add_zbuff_off(d0, rgb0, calib)
+    _, gx, gy = orc.intensity_sobel(rgb1)
+    I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+    poses = {}
+    for mode in ("allgather", "peer"):
+        ctx = pkg.Context(0)
+        ctx.set_calibration_matrix(calib)
+        ctx.alloc_buffers((n + 7) // 8, (m + 7) // 8)
+        al = multigpu.ShardedAligner(ctx, pkg.icp_params(), n, m, 0, 1, exchange=mode)
+        state = dev(np.concatenate([I, z, I, z]).astype(np.float32))
+        status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        for _ in range(2):                              # twice: the sequence words move on, stale lines must not pass
+            state.copy_(dev(np.concatenate([I, z, I, z]).astype(np.float32)))
+            al.align(dev(v1), dev(n1), dev(rgb1), dev(gx), dev(gy), dev(v0), dev(n0), dev(rgbd0), state, status)
+        ctx.synchronize()
+        poses[mode] = (state.cpu().numpy().copy(), status.cpu().numpy().copy())
+        ctx.close()
+    assert int(poses["peer"][1][0]) == 1 and int(poses["peer"][1][1]) >= 6
+    assert np.array_equal(poses["peer"][0], poses["allgather"][0]) and np.array_equal(poses["peer"][1], poses["allgather"][1])
+    ok, R, t, _ = orc.align_gauss_newton(orc.icp_params(), calib[:4], v1, n1, rgb1, v0, n0, rgbd0, I, z, I, z)
+    assert ok and np.array_equal(poses["peer"][0][:9], R) and np.array_equal(poses["peer"][0][9:12], t)   # one band = the single-GPU sums
+
+
+def test_rows_mode_two_ranks_on_one_card_peer_and_allgather():
+    size = ["--mode", "rows", "--rows", "240", "--cols", "320", "--steps", "4", "--warmup", "1"]
+    one = _bench(size + ["--exchange", "allgather"])
+    outs = {ex: _bench(size + ["--exchange", ex], world=2) for ex in ("allgather", "peer")}
+    assert one["n_gpus"] == 1 and all(o["n_gpus"] == 2 and o["scaling"] == "strong" for o in outs.values())
+    # the two exchange forms add the same numbers in the same order: identical bits
+    assert outs["peer"]["config"]["pose"] == outs["allgather"]["config"]["pose"]
+    assert outs["peer"]["config"]["icp_iterations_per_level"] == outs["allgather"]["config"]["icp_iterations_per_level"]
+    # against the unsharded run only the float32 summation order differs: BASELINE's 1e-5 rad / 1e-5 m bar
+    assert np.allclose(outs["peer"]["config"]["pose"], one["config"]["pose"], atol=1e-5, rtol=0)
+    assert "peer" in outs["peer"]["config"]["workload"]
+
+
+def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():
+    args = ["--mode", "planes", "--steps", "6", "--warmup", "2"]
+    one = _bench(args)
+    two = _bench(args, world=2)
+    assert one["config"]["planes_per_rank"] == 256 and two["config"]["planes_per_rank"] == 128
+    assert one["cells_fused"] > 100000
+    assert (one["model_checksum"], one["cells_fused"]) == (two["model_checksum"], two["cells_fused"])
+    for o in (one, two):
+        assert o["roofline"]["kernel"] == "k_vertex_from_bump_batch" and 0.0 < o["roofline"]["frac"] < 1.0
+        assert o["unit"] == "steps/s" and o["value"] > 0
