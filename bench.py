@@ -166,6 +166,44 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
                  "note": "k_hbm_stream, one 16-byte word per lane, workgroups in address order, 10 launches; copy counts read + written bytes"}
 
 
+def check_line(d, base_metric=None):
+    """The bench line's contract (keys the driver reads, roofline / CPU-baseline arithmetic).  bench.py runs it on its own
+    output before printing, tests/test_bench_contract.py runs it on the committed artefact and on a live GPU run."""
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, "missing key %s" % k
+    assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["vs_baseline"] is None
+    assert d["n_gpus"] >= 1 and d["steps"] > 0 and d["warmup"] >= 0 and d["value"] > 0
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    units = d["n_gpus"] if d["scaling"] == "weak" else 1          # weak: every rank processes `steps` units of its own
+    assert abs(d["value"] - 1e3 * units / d["ms_per_step"]) < 0.01 * d["value"], "value is not whole-job units / max time"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == HBM_PEAK_GBS
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    if base_metric is not None:
+        assert d["metric"] in base_metric
+    if d["metric"].startswith("ICP+fusion frames/sec"):
+        assert d["unit"] == "frames/s" and d["scaling"] == "weak"
+        gbs = r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9
+        assert abs(gbs - r["achieved"]) < 0.01 * r["achieved"], "achieved != algorithmic bytes per launch / average launch time"
+        assert r["event_pair_us"] > r["avg_launch_us"] > 0 and r["empty_event_pair_us"] > 0
+        if r["kernel"] in ("k_icp_iter", "k_icp_loop"):
+            px = [(d_["rows"] // f) * (d_["cols"] // f) for d_ in (d["config"],) for f in (1, 2, 4)]
+            want = 80 * sum(a * b for a, b in zip(r["icp_iterations_per_level"], px))
+            assert abs(r["algorithmic_bytes_per_frame"] - want) <= 0.01 * want + 80 * sum(px) / d["steps"]
+        c = d["cpu_baseline"]
+        if c is not None:
+            assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "frames/s" and c["value"] > 0 and c["sample"]
+        if d.get("value_with_h2d"):
+            assert 0 < d["value_with_h2d"]["value"] <= 1.05 * d["value"]
+    for k in d.get("hbm_bound_kernels") or []:
+        assert abs(k["frac"] - k["achieved"] / HBM_PEAK_GBS) < 1e-3 and 0 < k["frac_of_measured_stream"] < 1.5
+        gbs = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
+        assert abs(gbs - k["achieved"]) < 0.02 * k["achieved"]
+    return d
+
+
 def _max_over_ranks(env, seconds):
     if env["world"] == 1:
         return seconds
@@ -463,7 +501,7 @@ def main():
                "backend": backend}
         out = run_planes(args, env) if args.mode == "planes" else run_rows(args, env)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(check_line(out)), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -473,7 +511,7 @@ def main():
     total = args.warmup + args.steps + 1
     order = []
     k, d = 0, 1
-    for _ in range(total + args.steps):
+    for _ in range(total + args.steps + 340):
         order.append(k)
         if k + d < 0 or k + d >= POOL_FRAMES:
             d = -d
@@ -540,13 +578,22 @@ def main():
     if not args.profile_in_timed_region:
         lib.rgbdslam_profile_kernel(ctx, args.kernel.encode())
         run(order[pos:pos + args.steps])
-    li = host.slamhost_rg_last_level_iterations(rg._h)
-    level_iters = [li & 255, (li >> 8) & 255, (li >> 16) & 255]
+    # iteration counts of EVERY profiled frame (history ring: 16 floats per frame, [14] = executed iterations per level,
+    # 8 bits each), not just the last one's
+    fd = rg.frames_done()
+    hist = rg.history(fd - args.steps, args.steps)
+    packed = hist[:, 14].astype(np.int64)
+    per_level_total = [int(((packed >> (8 * k)) & 255).sum()) for k in range(3)]
+    level_iters = [round(t / float(args.steps), 2) for t in per_level_total]
     tot_ms, launches = C.c_double(), C.c_int()
     lib.rgbdslam_profile_read(ctx, C.byref(tot_ms), C.byref(launches))
     lib.rgbdslam_profile_kernel(ctx, None)
     per_frame_launches = launches.value / float(args.steps)
-    bytes_per_frame = algo_bytes(args.kernel, n, m, level_iters)
+    if args.kernel in ("k_icp_iter", "k_icp_loop"):
+        bytes_all_frames = algo_bytes(args.kernel, n, m, per_level_total)
+    else:
+        bytes_all_frames = PER_PX[args.kernel] * n * m * launches.value
+    bytes_per_frame = bytes_all_frames / float(args.steps)
     # every event pair carries the markers' own processing time on top of what it brackets: measured with empty
     # pairs on the same stream and taken off (one pair per frame: the pair around the loop kernel, or around the
     # twelve back-to-back k_icp_iter launches)
@@ -555,25 +602,50 @@ def main():
     pairs = args.steps if args.kernel in ("k_icp_iter", "k_icp_loop") else launches.value
     net_ms = max(0.0, tot_ms.value - pairs * ev_ms.value)
     avg_ms = net_ms / max(1, launches.value)
-    achieved = bytes_per_frame * args.steps / (net_ms * 1e-3) / 1e9 if net_ms > 0 else 0.0
+    achieved = bytes_all_frames / (net_ms * 1e-3) / 1e9 if net_ms > 0 else 0.0
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of
     # their own, profiles/*_pmc_traffic.json): counters cannot be read from inside this process
-    traffic = None
+    traffic = traffic_source = None
     try:
         if (n, m) != (480, 640):
             raise LookupError("the committed counter passes were taken at 640x480")
         import glob
-        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
-        t = pmc["bytes_per_launch"][args.kernel]
+        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+        pmc = json.load(open(pmc_file))
+        t = pmc["bytes_per_launch"].get(args.kernel) or pmc["bytes_per_launch"][args.kernel + "<false>"]
         traffic = t["fetch"] + t["write"]
+        traffic_source = {"file": os.path.relpath(pmc_file, ROOT), "source": pmc.get("source"),
+                          "note": "counters cannot be read from inside this process: separate rocprofv3 --pmc passes of this same command, committed"}
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": args.kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(bytes_per_frame / max(1.0, per_frame_launches)),
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_frame": round(per_frame_launches, 2),
                 "event_pair_us": round(tot_ms.value / max(1, pairs) * 1e3, 2), "empty_event_pair_us": round(ev_ms.value * 1e3, 2),
-                "algorithmic_bytes_per_frame": bytes_per_frame, "icp_iterations_per_level": level_iters}
+                "algorithmic_bytes_per_frame": int(bytes_per_frame), "icp_iterations_per_level": level_iters,
+                "icp_iterations_note": "mean executed iterations per level over all profiled frames (levels 0, 1, 2 = full, 1/2, 1/4 resolution)"}
+
+    # ---- PCIe-inclusive rate (never `value`): host-resident frames through RG::LoadFrame, 1.5 MB H2D per frame, pinned ----
+    value_with_h2d = None
+    if rank == 0 and world == 1:
+        hd = [torch.from_numpy(p[0]).pin_memory() for p in pool]
+        hb = [torch.from_numpy(p[1]).pin_memory() for p in pool]
+        nh = min(args.steps, 300)
+
+        def run_h2d(frames):
+            for i in frames:
+                host.slamhost_rg_load_frame(rg._h, C.c_void_p(hd[i].data_ptr()), C.c_void_p(hb[i].data_ptr()))
+                host.slamhost_rg_step_async(rg._h)
+            rg.synchronize()
+        hpos = pos + (0 if args.profile_in_timed_region else args.steps)    # where the device-resident passes stopped
+        run_h2d(order[hpos:hpos + 20])
+        h0 = time.perf_counter()
+        run_h2d(order[hpos + 20:hpos + 20 + nh])
+        value_with_h2d = {"value": round(nh / (time.perf_counter() - h0), 2), "unit": "frames/s", "frames": nh,
+                          "h2d_bytes_per_frame": n * m * 5,
+                          "note": "the same pipeline fed from pinned host memory (u16 depth + BGR8 uploaded per frame by RG::LoadFrame, "
+                                  "Frame.cpp:56-60); poses stay on the device"}
 
     # ---- CPU baseline: the oracle's display() loop on a bounded sample of the same sequence ----
     cpu = cpu_all = None
@@ -621,10 +693,10 @@ def main():
                "config": {"workload": "TUM fr1/xyz-shaped %dx%d RGB-D sequence (synthetic room corner, 1 mm depth noise), 3-level ICP "
                                       "(<= 3/4/5 iterations) + prediction + merge + Bump fusion into 3 planes of 1024x1024"
                                       % (m, n),
-                          "sequences": world, "frames_resident_in_hbm": True,
+                          "rows": n, "cols": m, "sequences": world, "frames_resident_in_hbm": True,
                           "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame"},
-               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
-        print(json.dumps(out), flush=True)
+               "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
+        print(json.dumps(check_line(out)), flush=True)
     rg.close()
     if world > 1:
         dist.destroy_process_group()

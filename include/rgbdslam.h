@@ -138,6 +138,17 @@ int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on);
 /* faults[0] = launches that gave up since the last call; synchronises the stream.  A fault switches the mode off. */
 int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults);
 
+/* The ICP kernels hand 128-byte lines (chain sums, loop state) between workgroups with relaxed agent-scope stores of one wave
+ * instruction and accept a line when the sequence word in each of its four 32-byte sectors is current -- which is sufficient
+ * only if gfx950 writes and reads such a sector indivisibly (measured so, not documented).  Every line also
+ * carries an integrity word (XOR of its payload); with the check switched on (or RGBDSLAM_ICP_LINE_CHECK=1 when the buffers are
+ * allocated) every accepted line is verified, a failing one is counted and read again, and the result no longer depends on that
+ * assumption (+ ~0.5 us per Gauss-Newton iteration).  rgbdslam_icp_line_rejections: count since the last call; synchronises. */
+int rgbdslam_set_icp_line_check(rgbdslam_ctx *ctx, int on);
+int rgbdslam_icp_line_rejections(rgbdslam_ctx *ctx, unsigned int *rejections);
+/* Debug: give-up time of the device-side waits in 10 ns ticks (default 5 000 000 = 50 ms; 0 = every waiter leaves at once). */
+int rgbdslam_debug_set_icp_timeout(rgbdslam_ctx *ctx, int ticks);
+
 /* Row-sharded form of the same loop (no reference counterpart: the reference is single-GPU;
  * SURVEY.md 8e / BASELINE.json configs[3]).  Each rank owns the 8x8-block rows
  * [block_row_lo, block_row_hi) of the level's block grid (divUp(n/2^lvl, 8) rows) and produces its

@@ -154,6 +154,17 @@ class Context:
         _chk(self.lib.rgbdslam_icp_loop_faults(self._h, C.byref(f)), "icp_loop_faults")
         return f.value
 
+    def set_icp_line_check(self, on):
+        _chk(self.lib.rgbdslam_set_icp_line_check(self._h, int(on)), "set_icp_line_check")
+
+    def icp_line_rejections(self):
+        r = C.c_uint(0)
+        _chk(self.lib.rgbdslam_icp_line_rejections(self._h, C.byref(r)), "icp_line_rejections")
+        return r.value
+
+    def debug_set_icp_timeout(self, ticks):
+        _chk(self.lib.rgbdslam_debug_set_icp_timeout(self._h, int(ticks)), "debug_set_icp_timeout")
+
     # -- stage 4 --
     def merge_depth_off(self, rgbd, depth, pitch, rgb, mask, n, m):
         _chk(self.lib.rgbdslam_merge_depth_off(self._h, _ptr(rgbd), _ptr(depth), C.c_size_t(pitch), _ptr(rgb), _ptr(mask), n, m),
@@ -390,6 +401,22 @@ class RG:
         f = C.c_int(0)
         _hchk(self.lib.slamhost_rg_icp_loop_faults(self._h, C.byref(f)), "icp_loop_faults")
         return f.value
+
+    def _ctx_ptr(self):
+        self.lib.slamhost_rg_ctx.restype = C.c_void_p
+        return C.c_void_p(self.lib.slamhost_rg_ctx(self._h))
+
+    def set_icp_line_check(self, on):
+        """Verify the integrity word of every line the ICP kernels hand between workgroups (rgbdslam_set_icp_line_check)."""
+        _chk(load().rgbdslam_set_icp_line_check(self._ctx_ptr(), int(on)), "set_icp_line_check")
+
+    def icp_line_rejections(self):
+        r = C.c_uint(0)
+        _chk(load().rgbdslam_icp_line_rejections(self._ctx_ptr(), C.byref(r)), "icp_line_rejections")
+        return r.value
+
+    def debug_set_icp_timeout(self, ticks):
+        _chk(load().rgbdslam_debug_set_icp_timeout(self._ctx_ptr(), int(ticks)), "debug_set_icp_timeout")
 
     def set_device_loop(self, on):
         _hchk(self.lib.slamhost_rg_set_device_loop(self._h, int(on)), "set_device_loop")

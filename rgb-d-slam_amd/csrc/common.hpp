@@ -43,6 +43,8 @@ struct rgbdslam_ctx {
     unsigned int *icp_epoch_dev;   // k_icp_loop: [0] epoch word, [32] fault flag
     unsigned int icp_epoch_base;   // host-side monotonic base of the epoch word
     int icp_loop;                  // rgbdslam_set_icp_loop
+    int icp_line_check;            // rgbdslam_set_icp_line_check
+    int icp_timeout_ticks;         // rgbdslam_debug_set_icp_timeout
     // instrumentation (rgbdslam_profile_*): HIP-event pairs around every launch of one named kernel
     const char *prof_name;
     hipEvent_t *prof_ev;   // 2 * prof_cap events

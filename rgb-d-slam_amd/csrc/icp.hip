@@ -152,6 +152,31 @@ __device__ __forceinline__ float add_shl(float v) {
     int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true);
     return v + __int_as_float(moved);
 }
+// ---- integrity word of a published 128-byte line (chain sums, loop state) ---------------------------------------------
+// Slot 30 of a line carries the XOR of its payload words (slots 0..29 without the tag slots 7, 15, 23).  A reader that has
+// accepted a line by its four sequence words can verify it (rgbdslam_set_icp_line_check): a line whose sectors were NOT
+// written or read indivisibly -- the hardware behaviour the sequence-word protocol relies on -- fails the check, is counted
+// (rgbdslam_icp_line_rejections) and is read again.  row_shr:N -- lane i receives lane i-N of its 16-lane row (0 before it).
+template <int N>
+__device__ __forceinline__ unsigned int xor_shr(unsigned int v) {
+    return v ^ (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true);
+}
+__device__ __forceinline__ bool icp_line_payload_slot(int slot) { return slot < 30 && (slot & 7) != 7; }
+// XOR of the payload words of the line held one word per lane in lanes 0..31 (wave-uniform result)
+__device__ __forceinline__ unsigned int icp_line_xor_lo(unsigned int word, int lane) {
+    unsigned int p = (lane < 32 && icp_line_payload_slot(lane)) ? word : 0u;
+    p = xor_shr<1>(p); p = xor_shr<2>(p); p = xor_shr<4>(p); p = xor_shr<8>(p);
+    return (unsigned int)__builtin_amdgcn_readlane((int)p, 15) ^ (unsigned int)__builtin_amdgcn_readlane((int)p, 31);
+}
+// both halves of the wave hold a line each (lanes 0..31 and 32..63): true when both match their slot-30 word
+__device__ __forceinline__ bool icp_lines_intact(unsigned int word, int lane) {
+    unsigned int p = icp_line_payload_slot(lane & 31) ? word : 0u;
+    p = xor_shr<1>(p); p = xor_shr<2>(p); p = xor_shr<4>(p); p = xor_shr<8>(p);
+    const unsigned int x0 = (unsigned int)__builtin_amdgcn_readlane((int)p, 15) ^ (unsigned int)__builtin_amdgcn_readlane((int)p, 31);
+    const unsigned int x1 = (unsigned int)__builtin_amdgcn_readlane((int)p, 47) ^ (unsigned int)__builtin_amdgcn_readlane((int)p, 63);
+    return x0 == (unsigned int)__builtin_amdgcn_readlane((int)word, 30) && x1 == (unsigned int)__builtin_amdgcn_readlane((int)word, 62);
+}
+
 // tr = this wave's LDS scratch [27][8]; returns the finished sum of term `lane` in lanes 0..26
 __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
     const bool row_head = (lane & 7) == 0;
@@ -216,6 +241,9 @@ struct IcpIterArgs {
     float *trace;
     long long *timing;                               // optional debug: phase time stamps (wall_clock64, 10 ns ticks)
     int *fault;                                      // optional: set to 1 when a wait gives up (rgbdslam_icp_loop_faults)
+    int line_check;                                  // verify the integrity word of every accepted line (rgbdslam_set_icp_line_check)
+    unsigned int *rejections;                        // lines that carried the right sequence words but failed the check
+    int timeout_ticks;                               // give-up time of the tail's wait (10 ns ticks)
     // track_frame path: the first launch builds the loop state itself (k_icp_begin), the last one
     // appends the track-loss test, the commit and the display() pose algebra (k_icp_end)
     int first_launch, final_launch;
@@ -236,7 +264,8 @@ struct IcpEndArgs { float *pose_state; int32_t *status; rgbdslam_pose_block *pb;
 // that executes (>= nsteps: finished) in the last slot of each 32-byte sector (slots 7, 15, 23, 31), stored after
 // the data has landed.  A reader takes the line with one wave-wide load and accepts it when all four copies
 // carry the new epoch: whatever way the memory system splits the line, every piece was then read after the data.
-struct IcpLoopCtl { unsigned int *pub; unsigned int base; int step, next_level, nsteps; };
+struct IcpLoopCtl { unsigned int *pub; unsigned int base; int step, next_level, nsteps, check; };
+#define ICP_OFF_REJECT_WORD 33   // unsigned words after the epoch word: [32] fault flag, [33] rejected lines
 #define ICP_PUB_DATA 25
 __device__ __forceinline__ constexpr int icp_pub_slot(int k) { return k + k / 7; }
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
@@ -425,7 +454,11 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         const float out = acc + part[ICP_CHAIN_WAVES][lane < 27 ? lane : 0];
         const int k = lane - (lane >> 3);             // term held by slot `lane`
         const float v = __shfl(out, k < 27 ? k : 0);
-        const unsigned int word = ((lane & 7) == 7) ? a.seq : __float_as_uint(v);
+        unsigned int word = ((lane & 7) == 7) ? a.seq : __float_as_uint(v);
+        if (a.line_check) {                               // slot 30: integrity word of the 27 sums
+            const unsigned int chk = icp_line_xor_lo(word, lane);
+            if (lane == 30) word = chk;
+        }
         if (lane < 32)
             __hip_atomic_store((unsigned int *)a.chains + 32 * icp_chain_line(t) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -460,8 +493,15 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
                 stale |= live && __float_as_uint(r[j]) != a.seq;
                 r[j] = live ? r[j] : 0.0f;
             }
-            if (__ballot(stale && is_seq) == 0ull) break;
-            if (wall_clock64() - t_poll > 5000000) {  // 50 ms: a workgroup of this step never ran (the device is not ours):
+            if (__ballot(stale && is_seq) == 0ull) {
+                if (!a.line_check) break;
+                bool intact = true;
+#pragma unroll
+                for (int j = 0; j < 16; j++) intact &= icp_lines_intact(__float_as_uint(r[j]), lane);
+                if (intact) break;
+                if (lane == 0 && a.rejections) atomicAdd(a.rejections, 1u);
+            }
+            if (wall_clock64() - t_poll > (long long)a.timeout_ticks) {  // 50 ms: a workgroup of this step never ran (the device is not ours):
 #pragma unroll
                 for (int j = 0; j < 16; j++) r[j] = __builtin_nanf("");   // the solve rejects the system, the frame counts as lost
                 if (a.fault && lane == 0) __hip_atomic_store(a.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -514,7 +554,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
                     bad |= live && y != a.xchg.seq;
                 }
                 if (__ballot(bad) == 0ull) break;
-                if (wall_clock64() - t_poll > 5000000) { gave_up = true; break; }   // 50 ms: a peer never published
+                if (wall_clock64() - t_poll > (long long)a.timeout_ticks) { gave_up = true; break; }   // 50 ms: a peer never published
                 __builtin_amdgcn_s_sleep(2);
             }
             // rank-ordered total (the order of k_icp_solve), through this wave's LDS scratch
@@ -551,7 +591,7 @@ __global__ __launch_bounds__(64 * ICP_MAX_WAVES)
 void k_icp_iter(IcpIterArgs a) {
     ICP_SHARED_DECL(S);
     IcpModelCache mc;
-    icp_iter_body<false>(a, S, IcpLoopCtl{nullptr, 0u, 0, 0, 0}, (int)threadIdx.x, (int)blockIdx.x, mc);
+    icp_iter_body<false>(a, S, IcpLoopCtl{nullptr, 0u, 0, 0, 0, 0}, (int)threadIdx.x, (int)blockIdx.x, mc);
 }
 
 // ---- persistent coarse-to-fine loop: ALL iterations of a frame in one launch -----------------------
@@ -594,6 +634,8 @@ struct IcpLoopArgs {
 #endif
 };
 
+// CHECK = rgbdslam_set_icp_line_check, a template parameter so that the default kernel carries none of the checking code
+template <bool CHECK>
 __global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(3)))
 void k_icp_loop(IcpLoopArgs L) {
     ICP_SHARED_DECL(S);
@@ -621,6 +663,8 @@ void k_icp_loop(IcpLoopArgs L) {
         if (t < min(nchain, ICP_WGS)) {
             IcpIterArgs a;
             a.xchg.world = 0; a.fault = (int *)(L.block + ICP_OFF_EPOCH + 128);
+            a.line_check = CHECK; a.rejections = (unsigned int *)(L.block + ICP_OFF_EPOCH) + ICP_OFF_REJECT_WORD;
+            a.timeout_ticks = L.timeout_ticks;
             a.intr = nullptr; a.R = nullptr; a.t = nullptr;
             a.VMap = L.VMap; a.NMap = L.NMap; a.RGB = L.RGB; a.Gx = L.Gx; a.Gy = L.Gy; a.gxp = L.gxp; a.gyp = L.gyp;
             a.VMap_prev = L.VMap_prev; a.NMap_prev = L.NMap_prev; a.RGBD_prev = L.RGBD_prev;
@@ -644,7 +688,7 @@ void k_icp_loop(IcpLoopArgs L) {
             for (int k = 0; k < 4; k++) a.intr4[k] = L.intr4[k];
             a.pose_state_rw = L.pb->pose_state; a.status = L.pb->status; a.pb = L.pb; a.history = L.history;
             a.frame_index = L.frame_index;
-            icp_iter_body<true>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps}, tid, t, mc);
+            icp_iter_body<true>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps, CHECK}, tid, t, mc);
         }
 #undef ICP_LV
         __syncthreads();                               // every thread is done with S
@@ -657,7 +701,10 @@ void k_icp_loop(IcpLoopArgs L) {
                 const unsigned int e0 = __builtin_amdgcn_readlane(w, 7), e1 = __builtin_amdgcn_readlane(w, 15),
                                    e2 = __builtin_amdgcn_readlane(w, 23), e3 = __builtin_amdgcn_readlane(w, 31);
                 const int d = (int)(e0 - L.epoch_base);
-                if (d > s && e1 == e0 && e2 == e0 && e3 == e0) { nxt = d; break; }
+                if (d > s && e1 == e0 && e2 == e0 && e3 == e0) {
+                    if (!CHECK || icp_line_xor_lo(w, tid) == (unsigned int)__builtin_amdgcn_readlane((int)w, 30)) { nxt = d; break; }
+                    if (tid == 0) atomicAdd((unsigned int *)(L.block + ICP_OFF_EPOCH) + ICP_OFF_REJECT_WORD, 1u);
+                }
                 if (wall_clock64() - t0 > (long long)L.timeout_ticks) { nxt = -1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -828,6 +875,57 @@ __device__ __forceinline__ int llt_solve6_reg(const float *sums, float *x) {
     return 0;
 }
 
+// The same solve spread over the lanes of one wave: lane r (0..5) owns ROW r of the factor.  Column k of the factor is
+// independent across rows, so its five divisions and dot products run side by side; the forward substitution is done
+// column by column (each row still subtracts its products in ascending column order, as the serial loop does) and the
+// backward substitution, whose rows must subtract in ascending order too, runs on the gathered factor.  Every element
+// sees exactly the operations of llt_solve6_reg in the same order: the bits are the same, the instruction count on the
+// critical path of the persistent loop drops from ~900 to ~400.  sums = 27 floats in LDS; x is valid in EVERY lane.
+__device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, float *x) {
+    const int r = lane < 6 ? lane : 5;
+    float Arow[6], Lr[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = r < k ? r : k, j = r < k ? k : r;
+        Arow[k] = sums[i * 7 - (i * (i - 1)) / 2 + (j - i)];     // SYM_A(sums, r, k), per-lane LDS address
+        Lr[k] = 0.0f;
+    }
+    float v = sums[r * 7 - (r * (r - 1)) / 2 + (6 - r)];         // b[r]
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        float s = Arow[k], w = Arow[k], Lk[6];
+#pragma unroll
+        for (int p = 0; p < k; p++) {
+            Lk[p] = lane_read(Lr[p], k);
+            s = s - Lr[p] * Lr[p];                               // meaningful in lane k
+            w = w - Lr[p] * Lk[p];                               // meaningful in lanes r > k
+        }
+        const float sk = lane_read(s, k);
+        if (!(sk > 0.0f)) return 1;
+        const float lkk = __builtin_sqrtf(sk);
+        Lr[k] = (r == k) ? lkk : w / lkk;
+    }
+    float y[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) {                                // forward: y[p], then every later row takes its product off
+        y[p] = lane_read(v, p) / lane_read(Lr[p], p);
+        v = v - Lr[p] * y[p];
+    }
+    float L[6][6];
+#pragma unroll
+    for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int c = 0; c <= p; c++) L[p][c] = lane_read(Lr[c], p);
+#pragma unroll
+    for (int q = 5; q >= 0; q--) {
+        float u = y[q];
+#pragma unroll
+        for (int p = q + 1; p < 6; p++) u = u - L[p][q] * x[p];
+        x[q] = u / L[q][q];
+    }
+    return 0;
+}
+
 // pose_state = poseR(9) poset(3) poseRPrev(9) posetPrev(3)
 __device__ __forceinline__ void d_set_rt_curr(IcpState *st, const float *ps) {
     float tmp[3];
@@ -895,8 +993,8 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
     if (wave == 1) {
         float det = wave_det6(sums, lane);                     // RG.cpp:862, concurrently with the solve
         if (lane == 0) sh[0] = det;
-    } else if (threadIdx.x == 0) {
-        llt_fail = llt_solve6_reg(sums, x);                    // RG.cpp:873
+    } else if (wave == 0) {
+        llt_fail = wave_llt_solve6(sums, lane, x);             // RG.cpp:873 (wave-uniform result)
     }
     __syncthreads();
     if (lc.pub ? wave != 0 : threadIdx.x != 0) return;
@@ -928,13 +1026,18 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         nxt = __builtin_amdgcn_readfirstlane(nxt);
-        if (lane < 32) {
+        {
             const int k = lane - (lane >> 3);                  // inverse of icp_pub_slot
-            unsigned int word = ((const unsigned int *)st)[k < 24 ? k : 0];
-            if (k == 24)
+            unsigned int word = 0u;
+            if (lane < 32 && k < 24) word = ((const unsigned int *)st)[k];
+            if (lane < 32 && k == 24)
                 word = (unsigned int)(st->lvl_iters & 0xffffff) | ((unsigned int)(st->cvg != 0) << 24) | ((unsigned int)(st->fail != 0) << 25);
             if ((lane & 7) == 7) word = lc.base + (unsigned int)nxt;
-            __hip_atomic_store(lc.pub + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lc.check) {                                    // slot 30: integrity word of the 25 data words
+                const unsigned int chk = icp_line_xor_lo(word, lane);
+                if (lane == 30) word = chk;
+            }
+            if (lane < 32) __hip_atomic_store(lc.pub + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (threadIdx.x == 0 && nxt >= lc.nsteps) icp_end_step(&loc, end);
         return;
@@ -962,7 +1065,7 @@ void k_icp_solve(IcpState *st, const float *__restrict__ gathered, int parts, co
     __syncthreads();
     if (sst.fail || (iter > 0 && sst.cvg)) return;
     icp_solve_step(&sst, st, sums, spose, lvl, iter, max_iter, thr_alpha, thr_tr, trace, sh, false, IcpEndArgs{nullptr, nullptr, nullptr, nullptr, 0},
-                   IcpLoopCtl{nullptr, 0u, 0, 0, 0});
+                   IcpLoopCtl{nullptr, 0u, 0, 0, 0, 0});
 }
 
 __device__ __forceinline__ void d_pack_pose(const float *R, const float *t, float *P) {   // GP-demo.cpp:206-211
@@ -1053,6 +1156,8 @@ extern "C" int rgbdslam_alloc_buffers(rgbdslam_ctx *ctx, int grid_rows, int grid
     if (!ctx->out_host) HIP_TRY(hipHostMalloc((void **)&ctx->out_host, 27 * sizeof(float), hipHostMallocDefault));
     const char *env = getenv("RGBDSLAM_ICP_LOOP");            // opt-in without touching the caller's code
     if (env && atoi(env) > 0) (void)rgbdslam_set_icp_loop(ctx, 1);
+    env = getenv("RGBDSLAM_ICP_LINE_CHECK");
+    if (env) ctx->icp_line_check = atoi(env) > 0;
     return 0;
 }
 
@@ -1072,14 +1177,14 @@ extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
     if (!on) { ctx->icp_loop = 0; return 0; }
     HIP_TRY(hipSetDevice(ctx->device));
     int per_cu = 0, cus = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_loop, 64 * ICP_MAX_WAVES, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_loop<true>, 64 * ICP_MAX_WAVES, 0));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
     if (cus <= 0 || (long)per_cu * cus < ICP_WGS) return RGBDSLAM_E_STATE;
     // The occupancy query packs waves freely over the four SIMDs of a CU; the dispatcher deals a workgroup's waves
     // to the SIMDs starting from the first one (measured with 5-wave workgroups: at 144 registers = 3 waves per SIMD
     // only ONE was resident per CU and the loop starved), so SIMD 0 must have room for every workgroup's share.
     hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_icp_loop));
+    HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_icp_loop<true>));
     const int regs = ((fa.numRegs > 0 ? fa.numRegs : 512) + 7) & ~7;
     const int waves_per_simd = 512 / regs < 8 ? 512 / regs : 8;
     const int wgs_per_cu = (ICP_WGS + cus - 1) / cus;
@@ -1107,6 +1212,38 @@ extern "C" int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults) {
     return 0;
 }
 
+// Integrity check of the published lines (chain sums, loop state): see icp_lines_intact.  With the check on, correctness no
+// longer rests on gfx950 writing and reading a wave instruction's 32-byte sector indivisibly; a rejected line is read again.
+extern "C" int rgbdslam_set_icp_line_check(rgbdslam_ctx *ctx, int on) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    ctx->icp_line_check = on != 0;
+    return 0;
+}
+// rejections[0] = lines that carried this step's sequence words but failed the integrity check, since the last call
+// (synchronises the stream).  Anything but 0 means the sector-atomicity assumption does not hold on this device.
+extern "C" int rgbdslam_icp_line_rejections(rgbdslam_ctx *ctx, unsigned int *rejections) {
+    if (!ctx || !rejections) return RGBDSLAM_E_ARG;
+    *rejections = 0;
+    if (!ctx->icp_epoch_dev) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned int r = 0;
+    HIP_TRY(hipMemcpyAsync(&r, ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (r) {
+        HIP_TRY(hipMemsetAsync(ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD, 0, sizeof(r), ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *rejections = r;
+    return 0;
+}
+// Debug: give-up time of every device-side wait of the ICP kernels in 10 ns ticks (default 5 000 000 = 50 ms); 0 makes every
+// waiter leave at once, which drives the give-up paths deterministically (tests).
+extern "C" int rgbdslam_debug_set_icp_timeout(rgbdslam_ctx *ctx, int ticks) {
+    if (!ctx || ticks < 0) return RGBDSLAM_E_ARG;
+    ctx->icp_timeout_ticks = ticks;
+    return 0;
+}
+
 struct IcpMaps {
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
     size_t gxp, gyp;
@@ -1128,6 +1265,8 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     IcpIterArgs a;
     if (xchg) a.xchg = *xchg; else a.xchg.world = 0;
     a.fault = ctx->icp_epoch_dev ? (int *)(ctx->icp_epoch_dev + 32) : nullptr;
+    a.line_check = ctx->icp_line_check; a.rejections = ctx->icp_epoch_dev ? ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD : nullptr;
+    a.timeout_ticks = ctx->icp_timeout_ticks;
     a.intr = intr; a.R = R; a.t = t;
     a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
     a.VMap_prev = mp.VMap_prev; a.NMap_prev = mp.NMap_prev; a.RGBD_prev = mp.RGB_prev;
@@ -1226,11 +1365,12 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
         L.nsteps = ns;
         L.epoch_base = ctx->icp_epoch_base;                    // this launch owns base+1 .. base+4095 (epochs and sequence
         ctx->icp_epoch_base += 4096u;                          // words): a stale word never releases a waiter or passes a check
-        L.timeout_ticks = 5000000;                             // 50 ms of the 100 MHz wall clock
+        L.timeout_ticks = ctx->icp_timeout_ticks;              // default 50 ms of the 100 MHz wall clock
 #ifdef ICP_LOOP_TIMING
         L.timing = ctx->icp_timing_dev;
 #endif
-        KLAUNCH(ctx, k_icp_loop, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
+        if (ctx->icp_line_check) KLAUNCH(ctx, k_icp_loop<true>, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
+        else KLAUNCH(ctx, k_icp_loop<false>, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
         HIP_TRY(hipGetLastError());
         return 0;
     }
