@@ -332,6 +332,16 @@ class Slam:
         nb = self._lib.orc_slam_detect_planes(self._h, int(min_size), int(min_normals), _p(eq), _p(ce))
         return eq[:nb], ce[:nb]
 
+    def set_finish(self, enabled=True, first_after=30, period=100, min_size=-1, min_normals=-1):
+        """RG::Finish schedule (D1/RG.cpp:149-271)."""
+        self._lib.orc_slam_set_finish(self._h, int(enabled), int(first_after), int(period), int(min_size), int(min_normals))
+
+    def finish_detections(self):
+        return int(self._lib.orc_slam_finish_detections(self._h))
+
+    def nb_planes(self):
+        return int(self._lib.orc_slam_nb_planes(self._h))
+
     def set_planes(self, equations, centers):
         eq = _f32(equations)
         self._lib.orc_slam_set_planes(self._h, _p(eq), _p(_f32(centers)), eq.size // 10)

@@ -1275,6 +1275,8 @@ struct orc_slam {
     float *Eq;
     uint32_t stamp;
     float poseR[9], poset[3], poseRPrev[9], posetPrev[3];
+    /* RG::Finish schedule (RG.cpp:149-271) */
+    int finish_enabled, finish_first_after, finish_period, finish_min_size, finish_min_normals, first_in, indx, finish_detections;
 };
 
 orc_slam *orc_slam_create(int n, int m, const float *calib, const orc_icp_params *prm,
@@ -1283,6 +1285,8 @@ orc_slam *orc_slam_create(int n, int m, const float *calib, const orc_icp_params
     size_t P = (size_t)n * m;
     s->n = n; s->m = m; s->max_planes = max_planes; s->N_prim = N_prim; s->M_prim = M_prim;
     s->znear = znear; s->zfar = zfar; s->count = 1;                              /* RG.h:112 */
+    s->finish_enabled = 1; s->finish_first_after = 30; s->finish_period = 100;   /* RG.cpp:154,187 */
+    s->finish_min_size = 5000; s->finish_min_normals = 1000; s->first_in = 1;    /* Utilities.h:85, RG.cpp:500, RG.h:194 */
     memcpy(s->calib, calib, sizeof(s->calib));
     memcpy(s->intr, calib, sizeof(s->intr));
     s->prm = *prm;
@@ -1448,8 +1452,30 @@ int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr) {
                    s->Label, Pg, s->N_prim, s->M_prim, n, m, 0, s->nb_planes);
     }
     (void)P;
+    /* 12. RG::Finish (GP-demo.cpp:274, RG.cpp:149-271; the dump is file I/O and lives in the host library, ReorganizeEqua's
+     * output is overwritten by the detection that follows it) */
+    if (s->finish_enabled) {
+        if (s->first_in && s->count > s->finish_first_after) {                   /* RG.cpp:154-175 */
+            orc_slam_detect_planes(s, s->finish_min_size, s->finish_min_normals, NULL, NULL);
+            s->first_in = 0;
+            s->finish_detections++;
+        } else if (s->finish_period > 0 && (s->count % s->finish_period) == 0) { /* RG.cpp:187-270 */
+            memcpy(s->poseRPrev, s->poseR, 36); memcpy(s->posetPrev, s->poset, 12);
+            s->indx++;
+            orc_slam_detect_planes(s, s->finish_min_size, s->finish_min_normals, NULL, NULL);
+            s->finish_detections++;
+        }
+    }
     return first ? 2 : 1;
 }
+
+void orc_slam_set_finish(orc_slam *s, int enabled, int first_after, int period, int min_size, int min_normals) {
+    s->finish_enabled = enabled; s->finish_first_after = first_after; s->finish_period = period;
+    if (min_size >= 0) s->finish_min_size = min_size;
+    if (min_normals >= 0) s->finish_min_normals = min_normals;
+}
+int orc_slam_finish_detections(const orc_slam *s) { return s->finish_detections; }
+int orc_slam_nb_planes(const orc_slam *s) { return s->nb_planes; }
 
 void orc_slam_get_pose(const orc_slam *s, float *R, float *t) { memcpy(R, s->poseR, 36); memcpy(t, s->poset, 12); }
 

@@ -491,6 +491,17 @@ class RG:
         _hchk(self.lib.slamhost_rg_get_planes(self._h, C.c_void_p(eq.ctypes.data), C.c_void_p(ce.ctypes.data), cap), "get_planes")
         return eq[:nb.value], ce[:nb.value]
 
+    def set_finish(self, enabled=True, first_after=30, period=100, save_dir=None, min_size=-1, min_normals=-1):
+        """RG::Finish schedule (D1/RG.cpp:149-271): first plane detection when _count > first_after, then every `period`
+        frames dump (into save_dir, if given) + plane reset + re-detection; period 0 = never."""
+        _hchk(self.lib.slamhost_rg_set_finish(self._h, int(enabled), int(first_after), int(period),
+                                              os.fsencode(save_dir) if save_dir else None, int(min_size), int(min_normals)), "set_finish")
+
+    def finish_stats(self):
+        out = (C.c_int * 4)()
+        _hchk(self.lib.slamhost_rg_finish_stats(self._h, out), "finish_stats")
+        return {"detections": out[0], "dumps": out[1], "planes": out[2], "indx": out[3]}
+
     def save_model(self, directory, indx):
         """Saving half of RG::Finish + SaveThread (D1/RG.cpp:16-59): cleaned planes + key frame in the reference's dump format."""
         _hchk(self.lib.slamhost_rg_save_model(self._h, os.fsencode(directory), int(indx)), "save_model")

@@ -830,7 +830,10 @@ void RG::DetectPrimitives(float *pose) {
             Nz[j] = (N[0] * pose[2] + N[1] * pose[6]) + N[2] * pose[10];
         }
         if (count < min_normals_plan) continue;                                       // RG.cpp:500-516
-        std::sort(Nx.begin(), Nx.end()); std::sort(Ny.begin(), Ny.end()); std::sort(Nz.begin(), Nz.end());   // RG.cpp:521-533
+        // RG.cpp:521-533 sorts the three lists and takes the middle elements: the same elements by selection
+        std::nth_element(Nx.begin(), Nx.begin() + Nx.size() / 2, Nx.end());
+        std::nth_element(Ny.begin(), Ny.begin() + Ny.size() / 2, Ny.end());
+        std::nth_element(Nz.begin(), Nz.begin() + Nz.size() / 2, Nz.end());
         float nmle[3] = {Nx[Nx.size() / 2], Ny[Ny.size() / 2], Nz[Nz.size() / 2]};
         float norm_nmle = sqrtf((nmle[0] * nmle[0] + nmle[1] * nmle[1]) + nmle[2] * nmle[2]);
         nmle[0] = nmle[0] / norm_nmle; nmle[1] = nmle[1] / norm_nmle; nmle[2] = nmle[2] / norm_nmle;
@@ -847,7 +850,7 @@ void RG::DetectPrimitives(float *pose) {
             Label_cpu[px[j]] = (uint8_t)(_nbPlan + 1);
         }
         for (int k = 0; k < 3; k++) _Centers.push_back(center_curr[k] / (float)curr_size);   // RG.cpp:581-583
-        std::sort(Dists.begin(), Dists.end());                                        // RG.cpp:592-598
+        std::nth_element(Dists.begin(), Dists.begin() + Dists.size() / 2, Dists.end());   // RG.cpp:592-598 (sort + middle element)
         const float dist = Dists[Dists.size() / 2];
         float e1[3], e2[3];                                                           // RG.cpp:607-637
         if (nmle[0] > nmle[1] && nmle[0] > nmle[2]) { e1[0] = -nmle[1]; e1[1] = nmle[0]; e1[2] = 0.0f; }
@@ -874,6 +877,36 @@ int RG::DetectPlanes() {                                                        
     DetectPrimitives(pose);
     CreatePrimitives(pose, true);
     return _nbPlan;
+}
+
+// RG.cpp:149-271.  ReorganizeEqua (RG.cpp:266, 934-1006) is not run: everything it produces -- remapped labels, compacted
+// equations / centres, _nbPlan -- is overwritten by the DetectPrimitives call that follows it (labels cleared RG.cpp:313,
+// _nbPlan = 0 RG.cpp:401); its two kernels exist as rgbdslam_vote_plan / rgbdslam_affect_plan for callers that want them.
+void RG::Finish() {
+    if (!finish_enabled) return;
+    const bool first_due = _first_in && _count > finish_first_after;                  // RG.cpp:154
+    const bool period_due = !first_due && finish_period > 0 && (_count % finish_period) == 0;   // RG.cpp:187
+    if (!first_due && !period_due) return;
+    if (fused) {
+        if (Sync() == 0) return;                                                      // lost frame: display() jumps over Finish
+    }
+    if (first_due) {
+        DetectPlanes();                                                               // RG.cpp:163-169
+        _first_in = false;
+        finish_detections++;
+        return;
+    }
+    bool ok2Save = !save_dir.empty();
+    if (ok2Save) {                                                                    // RG.cpp:177-184
+        FILE *f = fopen((save_dir + "/Dummy.txt").c_str(), "r");
+        if (f) { ok2Save = false; fclose(f); }
+    }
+    _poseRPrev = _poseR;                                                              // RG.cpp:189-190
+    _posetPrev = _poset;
+    if (ok2Save) { SaveModel(save_dir.c_str(), _indx); finish_dumps++; }              // RG.cpp:209-232 (+ SaveThread, RG.cpp:16-59)
+    _indx++;                                                                          // RG.cpp:234
+    DetectPlanes();                                                                   // RG.cpp:253-268: tables freed, planes re-detected
+    finish_detections++;
 }
 
 void RG::CreatePrimitives(float *pose, bool labels_from_detection) {
@@ -980,6 +1013,7 @@ int RG::StepAsync() {
     }
     _next_hint.valid = false;
     frames_done++;
+    Finish();                                                                       // GP-demo.cpp:274
     return first ? 2 : 1;
 }
 
@@ -1066,6 +1100,7 @@ int RG::Step() {
     _posetPrev = _poset;
     _predicted_frame->Merge(_frame);                                                // GP-demo.cpp:249
     _graph->Update(_predicted_frame, pose);                                         // GP-demo.cpp:260
+    Finish();                                                                       // GP-demo.cpp:274
     return first ? 2 : 1;
 }
 
@@ -1393,6 +1428,24 @@ int slamhost_rg_detect_planes(void *rg, int min_size, int min_normals, int *nb) 
     int k = 0;
     FACADE_TRY(k = r->DetectPlanes());
     if (nb) *nb = k;
+    return 0;
+}
+// RG::Finish schedule: enabled, first detection when _count > first_after, dump + re-detection when _count % period == 0
+// (period 0 = never); save_dir NULL / "" = no dump; min_size / min_normals >= 0 override MIN_SIZE_PLAN / 1000 (small images)
+int slamhost_rg_set_finish(void *rg, int enabled, int first_after, int period, const char *save_dir, int min_size, int min_normals) {
+    if (!rg || first_after < 0 || period < 0) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    r->finish_enabled = enabled != 0; r->finish_first_after = first_after; r->finish_period = period;
+    r->save_dir = save_dir ? save_dir : "";
+    if (min_size >= 0) r->min_size_plan = min_size;
+    if (min_normals >= 0) r->min_normals_plan = min_normals;
+    return 0;
+}
+// [0] detections run by Finish, [1] dumps written, [2] current plane count, [3] _indx
+int slamhost_rg_finish_stats(void *rg, int *out4) {
+    if (!rg || !out4) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    out4[0] = r->finish_detections; out4[1] = r->finish_dumps; out4[2] = r->_nbPlan; out4[3] = r->_indx;
     return 0;
 }
 int slamhost_rg_get_planes(void *rg, float *equations, float *centers, int cap) {

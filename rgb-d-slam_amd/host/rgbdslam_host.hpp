@@ -253,6 +253,17 @@ public:
     // (RG.cpp:154-175): DetectPrimitives + CreatePrimitives on the current model frame; returns the plane count.
     void DetectPrimitives(float *pose);
     int DetectPlanes();
+    // RG::Finish (RG.cpp:149-271), step 12 of display() (GP-demo.cpp:274): the first plane detection once _count > 30, then
+    // every 100 frames the dump of the model (SaveModel into save_dir; synchronous -- the reference's Win32 SaveThread is
+    // out of scope -- and skipped when save_dir is empty or holds a file Dummy.txt, RG.cpp:177-184), the reset of the plane
+    // set and a new detection.  Step() / StepAsync() call it; a frame whose tracking was lost skips it (GP-demo.cpp:196).
+    void Finish();
+    bool finish_enabled = true;
+    int finish_first_after = 30, finish_period = 100;              // RG.cpp:154,187
+    std::string save_dir;
+    bool _first_in = true;                                         // RG.h:74,194
+    int _indx = 0;                                                 // RG.h:49,164
+    int finish_detections = 0, finish_dumps = 0;
     int min_size_plan = 5000;                                      // MIN_SIZE_PLAN (Utilities.h:85)
     int min_normals_plan = 1000;                                   // RG.cpp:500
     bool _Detect = false;

@@ -37,6 +37,7 @@ def test_soak_2000_frames_loop_kernel_with_line_check(pkg, synth):
     hist = {}
     for mode in ("loop+check", "multi-launch"):
         rg = pkg.RG(n, m, calib)
+        rg.set_finish(False)                                     # planes are injected once; no re-detection cycles in the soak
         if mode == "loop+check":
             rg.set_icp_loop(True)
             rg.set_icp_line_check(True)

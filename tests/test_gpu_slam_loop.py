@@ -4,6 +4,8 @@ HIP C ABI against the CPU oracle's restatement, frame by frame, on the same synt
 Bar: poses within 1e-5 rad / 1e-5 m per frame (north_star) -- in fact required bit-identical here,
 like every map, mask, label and Bump image, because both sides evaluate the same IEEE operations in
 the same order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -423,5 +425,67 @@ def test_next_frame_hint_true_false_and_absent(pkg, orc, synth):
     same(hist[5, 9:12], t, "poset")
     for name in ("VMap", "NMap", "RGBD", "Mask", "Label", "Maskb0", "Bump1", "RGBb2"):
         same(rg.buffer(name), ref.buffer(name), name)
+    rg.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_finish_schedule_first_detection_and_periodic_cycle(pkg, orc, synth, tmp_path, fused):
+    """RG::Finish (D1/RG.cpp:149-271, step 12 of display()): NO planes are injected -- Step() detects them itself once
+    _count > 30, and when _count % 100 == 0 it dumps the model, resets the plane set and detects again.  132 frames at
+    120 x 160 against the oracle with the same schedule: poses, model maps, labels and Bump images bit-exact right after the
+    first detection, right before and after the periodic cycle, and at the end; the dump of the cycle is on disk."""
+    n, m, frames, N_prim = 120, 160, 132, 256
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(60, n, m, calib)
+    order, k, d = [], 0, 1
+    for _ in range(frames):
+        order.append(k)
+        if k + d < 0 or k + d >= 60:
+            d = -d
+        k += d
+    ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    ref.set_finish(True, 30, 100, 300, 200)
+    rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg.set_fused(fused)
+    rg.set_finish(True, 30, 100, str(tmp_path), 300, 200)
+
+    def compare(f):
+        nb = ref.nb_planes()
+        assert rg.finish_stats()["planes"] == nb
+        for name in ("VMap", "NMap", "RGBD", "Mask", "Label"):
+            same(rg.buffer(name), ref.buffer(name), "frame %d %s" % (f, name))
+        for p in range(nb):
+            same(rg.buffer("Maskb%d" % p), ref.buffer("Maskb%d" % p), "frame %d Maskb%d" % (f, p))
+            same(rg.buffer("Bump%d" % p), ref.buffer("Bump%d" % p), "frame %d Bump%d" % (f, p))
+            same(rg.buffer("RGBb%d" % p), ref.buffer("RGBb%d" % p), "frame %d RGBb%d" % (f, p))
+
+    for f, i in enumerate(order):
+        dd, cc = seq[i]
+        st_ref = ref.step(dd, cc)
+        rg.load_frame(dd, cc)
+        assert rg.step() == st_ref, "frame %d" % f
+        R, t = rg.pose()
+        Rr, tr = ref.pose()
+        same(np.array(R, np.float32), Rr, "frame %d poseR" % f)
+        same(np.array(t, np.float32), tr, "frame %d poset" % f)
+        # _count = f + 2 after frame f: first detection at f = 29 (_count 31), cycle at f = 98 (_count 100)
+        if f == 28:
+            assert rg.finish_stats()["detections"] == 0 and ref.nb_planes() == 0
+        if f in (29, 30, 97, 98, 99, frames - 1):
+            compare(f)
+        if f == 29:
+            assert rg.finish_stats() == {"detections": 1, "dumps": 0, "planes": 3, "indx": 0} and ref.finish_detections() == 1
+        if f == 97:
+            filled = sum(int((ref.buffer("Maskb%d" % p) > 10).sum()) for p in range(3))
+            assert filled > 3000, "the planes detected at frame 29 were fused into"
+        if f == 98:
+            assert rg.finish_stats() == {"detections": 2, "dumps": 1, "planes": 3, "indx": 1} and ref.finish_detections() == 2
+            assert all(int((ref.buffer("Maskb%d" % p) > 10).sum()) == 0 for p in range(3)), "the cycle starts the plane set afresh"
+    # the dump of the cycle, in the reference's format (Graph::save / PredictedFrame::save)
+    names = sorted(os.listdir(tmp_path))
+    assert "Graph-eq0.txt" in names and "Pose1.txt" in names and any(x.startswith("Bump0-") for x in names), names
+    model = pkg.load_model(str(tmp_path), 0)
+    assert model is not None and len(model["planes"]) == 3
     rg.close()
     ref.close()
