@@ -433,6 +433,22 @@ int rgbdslam_detect_regions(rgbdslam_ctx *ctx, const float *NMap, const float *V
                             double canny_low, double canny_high, float thresh_discont, uint8_t thresh_edge,
                             int32_t *blob, int32_t *sizes, int32_t *work_labels, uint8_t *work_bytes, int n, int m);
 
+/* ---- prediction of the model directly from the Bump images (BASELINE configs[2] "fusion +
+ * raycast partitioned by plane").  No call site in DemoStep1's loop (it predicts from the previous depth image); the meshes are
+ * the reference's: VertexFromBump (Primitive.cuh:16, Primitive.cu:31-93) + QuadTrim (Primitive.cuh:18, Primitive.cu:95-152).
+ * planes_draw rasterises the trimmed quad meshes of planes [plane_lo, plane_hi) -- transformed by the world -> camera pose
+ * (HOST pointer, 16 floats column-major) -- into zbuf (u64[n*m], 0xFF-filled by rgbdslam_raster_clear; NOT cleared here) with
+ * the rasteriser rules of rgbdslam_predict_raster; key = f32 depth << 32 | ~(((plane*(N-1)*(M-1) + quad)*2 + t)).  Z-buffers of
+ * disjoint plane ranges merge by an elementwise u64 minimum (multi-GPU: one all-reduce).  planes_resolve turns the pixels won by
+ * planes [plane_lo, plane_hi) into VMap (f32x3) and RGBD (r, g, b, depth/100) as ReadFrame_cu does (Kernel.cu:309-343); empty
+ * pixels become zeros (written when plane_lo == 0); other pixels are left alone.  min_conf >= 1 (Primitive.cu:135). */
+int rgbdslam_planes_draw(rgbdslam_ctx *ctx, uint64_t *zbuf, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab,
+                         float **ParamTab, int plane_lo, int plane_hi, const float *pose_world_to_cam16_host, int N_prim,
+                         int M_prim, unsigned short min_conf, float thresh, float znear, float zfar, int n, int m);
+int rgbdslam_planes_resolve(rgbdslam_ctx *ctx, uint64_t *zbuf, float *VMap, float *RGBD, uint16_t **BumpTab, uint8_t **RGBTab,
+                            uint8_t **MaskTab, float **ParamTab, int plane_lo, int plane_hi,
+                            const float *pose_world_to_cam16_host, int N_prim, int M_prim, int reset_zbuf, int n, int m);
+
 /* ---- 16-bit labels: models of more than 255 planes (BASELINE configs[2], 256 planes).  No reference counterpart: the
  * reference's label image is u8 (Frame.h:197; label 0 = none, L = plane L-1, Primitive.cu:279-281), which caps a model at 255
  * planes.  rgbdslam_update / rgbdslam_update_from_history with a u16 label image; same kernels, same winner rule. */

@@ -528,3 +528,20 @@ def label_planes_l16(vmap, nmap, pose, params, N_prim, M_prim, eps=0.1, alpha=0.
     lib().orc_label_planes_l16(_p(out), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _ptr_table(params), len(params),
                                N_prim, M_prim, C.c_float(eps), C.c_float(alpha), n, m)
     return out
+
+
+# ---- prediction from the planes ---------------------------------------------------------------------------
+def planes_draw(zbuf, bumps, rgbs, masks, params, plane_lo, plane_hi, pose_w2c, calib, n, m, min_conf=0, thresh=0.1, znear=0.5, zfar=10.0,
+                size=None):
+    """In place on zbuf (np.uint64 [n, m], start from 0xFFFF...)."""
+    N, M = size if size is not None else masks[0].shape
+    lib().orc_planes_draw(_p(zbuf), _ptr_table(bumps), _ptr_table(rgbs), _ptr_table(masks), _ptr_table(params), plane_lo, plane_hi,
+                          _p(_f32(pose_w2c)), N, M, int(min_conf), C.c_float(thresh), _p(_f32(calib)), C.c_float(znear), C.c_float(zfar), n, m)
+
+
+def planes_resolve(zbuf, vmap, rgbd, bumps, rgbs, masks, params, plane_lo, plane_hi, pose_w2c, calib, size=None):
+    """In place on vmap [n, m, 3] / rgbd [n, m, 4] (float32)."""
+    n, m = zbuf.shape
+    N, M = size if size is not None else masks[0].shape
+    lib().orc_planes_resolve(_p(zbuf), _p(vmap), _p(rgbd), _ptr_table(bumps), _ptr_table(rgbs), _ptr_table(masks), _ptr_table(params),
+                             plane_lo, plane_hi, _p(_f32(pose_w2c)), N, M, _p(_f32(calib)), n, m)

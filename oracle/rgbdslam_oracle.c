@@ -1021,6 +1021,114 @@ void orc_raster(float *tex, uint64_t *zbuf, const float *VMap, const float *RGBD
         }
 }
 
+/* ---- prediction from the planes (no D1 call site: the Bump meshes -- VertexFromBump,
+ * Primitive.cu:31-93, + QuadTrim, Primitive.cu:95-152 -- drawn by the same rasteriser rules as the frame mesh) ------------
+ * decode of ONE cell: the arithmetic of orc_vertex_from_bump at lvl 1 */
+static void decode_one(const uint16_t *Bump, const uint8_t *RGBb, const uint8_t *Mask, const float *param, int M, int i, int j,
+                       float *v, float *rgb) {
+    size_t ref = (size_t)i * M + j;
+    if (Mask[ref] < 11 && Mask[ref] != 1) { v[0] = v[1] = v[2] = 0.0f; rgb[0] = rgb[1] = rgb[2] = 0.0f; return; }
+    float s0 = (float)((double)(float)Bump[3 * ref] / 60000.0), s1 = (float)((double)(float)Bump[3 * ref + 1] / 60000.0);
+    float x = (float)((double)((float)i + s0) * 2.0 / (double)param[4] + (double)param[6]);
+    float y = (float)((double)((float)j + s1) * 2.0 / (double)param[5] + (double)param[7]);
+    float d = (float)((double)param[3] + (((double)(float)Bump[3 * ref + 2] / 2000.0) - 15.0));
+    v[0] = (x * param[8] + y * param[11]) + d * param[0];
+    v[1] = (x * param[9] + y * param[12]) + d * param[1];
+    v[2] = (x * param[10] + y * param[13]) + d * param[2];
+    for (int c = 0; c < 3; c++) rgb[c] = (float)((double)(float)RGBb[3 * ref + c] / 255.0);
+}
+static void xf16(const float *P, const float *a, float *o) {
+    o[0] = ((P[0] * a[0] + P[4] * a[1]) + P[8] * a[2]) + P[12];
+    o[1] = ((P[1] * a[0] + P[5] * a[1]) + P[9] * a[2]) + P[13];
+    o[2] = ((P[2] * a[0] + P[6] * a[1]) + P[10] * a[2]) + P[14];
+}
+/* the four corner cells of quad (i, j): (i,j) (i,j+1) (i+1,j+1) (i+1,j), the order of QuadTrim's record */
+static const int QC_I[4] = {0, 0, 1, 1}, QC_J[4] = {0, 1, 1, 0};
+
+/* z-buffer pass over planes [plane_lo, plane_hi); zbuf is NOT cleared (callers start from ZBUF_EMPTY and may draw plane
+ * ranges one after the other: the minimum is commutative).  pose = world -> camera, column-major 4x4.
+ * triangle id = ((plane * (N-1)*(M-1) + quad) * 2 + t), t = 0: corners (0,1,2), t = 1: corners (0,2,3). */
+void orc_planes_draw(uint64_t *zbuf, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, int plane_lo,
+                     int plane_hi, const float *pose, int N, int M, int min_conf, float thresh, const float *calib, float znear,
+                     float zfar, int n, int m) {
+    const uint32_t Q = (uint32_t)(N - 1) * (uint32_t)(M - 1);
+    for (int k = plane_lo; k < plane_hi; k++) {
+        #pragma omp parallel for schedule(static)
+        for (int i = 0; i < N - 1; i++)
+            for (int j = 0; j < M - 1; j++) {
+                float vw[12], vc[12], rgb[3];
+                int cut = 0;
+                for (int c = 0; c < 4; c++) {
+                    int ci = i + QC_I[c], cj = j + QC_J[c];
+                    cut |= corner_rejected(MaskTab[k][(size_t)ci * M + cj], min_conf, 0);
+                    decode_one(BumpTab[k], RGBTab[k], MaskTab[k], ParamTab[k], M, ci, cj, vw + 3 * c, rgb);
+                }
+                uint32_t id4[4] = {0, 1, 2, 3};
+                cut |= quad_trimmed(vw, id4, thresh);
+                if (cut) continue;
+                for (int c = 0; c < 4; c++) xf16(pose, vw + 3 * c, vc + 3 * c);
+                uint32_t q = (uint32_t)i * (uint32_t)(M - 1) + (uint32_t)j;
+                uint32_t base = ((uint32_t)k * Q + q) * 2u;
+                uint32_t t0[3] = {0, 1, 2}, t1[3] = {0, 2, 3};
+                ras_draw(zbuf, vc, t0, base, calib, znear, zfar, n, m);
+                ras_draw(zbuf, vc, t1, base + 1, calib, znear, zfar, n, m);
+            }
+    }
+}
+
+/* resolve + the ReadKernel arithmetic (Kernel.cu:309-343): pixels whose winning triangle belongs to a plane in
+ * [plane_lo, plane_hi) get VMap / RGBD (r, g, b, depth/100), empty pixels get zeros, other pixels are left alone */
+void orc_planes_resolve(const uint64_t *zbuf, float *VMap, float *RGBD, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab,
+                        float **ParamTab, int plane_lo, int plane_hi, const float *pose, int N, int M, const float *calib, int n, int m) {
+    const uint32_t Q = (uint32_t)(N - 1) * (uint32_t)(M - 1);
+    #pragma omp parallel for schedule(static)
+    for (int py = 0; py < n; py++)
+        for (int px = 0; px < m; px++) {
+            size_t p = (size_t)py * m + px;
+            uint64_t key = zbuf[p];
+            if (key == ZBUF_EMPTY) {                                              /* written by the owner of plane 0 only */
+                if (plane_lo == 0) {
+                    VMap[3 * p] = VMap[3 * p + 1] = VMap[3 * p + 2] = 0.0f;
+                    RGBD[4 * p] = RGBD[4 * p + 1] = RGBD[4 * p + 2] = RGBD[4 * p + 3] = 0.0f;
+                }
+                continue;
+            }
+            uint32_t tri_id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+            uint32_t k = (tri_id >> 1) / Q, q = (tri_id >> 1) % Q;
+            if ((int)k < plane_lo || (int)k >= plane_hi) continue;
+            int i = (int)(q / (uint32_t)(M - 1)), j = (int)(q % (uint32_t)(M - 1));
+            const int c3[2][3] = {{0, 1, 2}, {0, 2, 3}};
+            float vc[9], att[3][4];
+            for (int e = 0; e < 3; e++) {
+                int c = c3[tri_id & 1][e];
+                float vw[3];
+                decode_one(BumpTab[k], RGBTab[k], MaskTab[k], ParamTab[k], M, i + QC_I[c], j + QC_J[c], vw, att[e]);
+                xf16(pose, vw, vc + 3 * e);
+                float z = vc[3 * e + 2];
+                att[e][3] = ((double)(-z) > MAX_DEPTH || (double)(-z) < 0.0) ? 0.0f : (float)((double)(-z) / MAX_DEPTH);   /* Kernel.cu:371 */
+            }
+            uint32_t vid[3] = {0, 1, 2};
+            ras_tri T; int order[3]; int64_t w[3];
+            ras_setup(vc, vid, calib, &T, order);
+            ras_cover(&T, px, py, w);
+            double b0 = (double)w[0] * T.inv_d[0], b1 = (double)w[1] * T.inv_d[1], b2 = (double)w[2] * T.inv_d[2];
+            double W = (b0 + b1) + b2;
+            float tx[4];
+            for (int c = 0; c < 4; c++)
+                tx[c] = (float)(((b0 * (double)att[order[0]][c] + b1 * (double)att[order[1]][c]) + b2 * (double)att[order[2]][c]) / W);
+            if (tx[3] == 0.0f) {
+                VMap[3 * p] = VMap[3 * p + 1] = VMap[3 * p + 2] = 0.0f;
+                RGBD[4 * p] = RGBD[4 * p + 1] = RGBD[4 * p + 2] = RGBD[4 * p + 3] = 0.0f;
+                continue;
+            }
+            float z = (float)((double)tx[3] * MAX_DEPTH);
+            VMap[3 * p]     = z * (((float)px - calib[2]) / calib[0]);
+            VMap[3 * p + 1] = z * (((float)py - calib[3]) / calib[1]);
+            VMap[3 * p + 2] = -z;
+            for (int c = 0; c < 4; c++) RGBD[4 * p + c] = tx[c];
+        }
+}
+
 void orc_read_frame(float *VMap, float *RGBD, const float *tex, const float *calib, int n, int m) {
     memset(RGBD, 0, sizeof(float) * 4 * (size_t)n * m);                          /* Kernel.cu:900 */
     #pragma omp parallel for schedule(static)

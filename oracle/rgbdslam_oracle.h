@@ -207,4 +207,13 @@ void orc_update_l16(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, flo
 void orc_label_planes_l16(uint16_t *Label16, const float *VMap, const float *NMap, const float *pose, float **ParamTab, int nb,
                           int N_prim, int M_prim, float epsilon, float alpha, int n, int m);
 
+/* prediction from the planes: the Bump meshes (VertexFromBump Primitive.cu:31-93 + QuadTrim Primitive.cu:95-152) drawn with the
+ * rasteriser rules of orc_raster; checkers of rgbdslam_planes_draw / rgbdslam_planes_resolve */
+void orc_planes_draw(uint64_t *zbuf, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, int plane_lo,
+                     int plane_hi, const float *pose_world_to_cam, int N, int M, int min_conf, float thresh, const float *calib,
+                     float znear, float zfar, int n, int m);
+void orc_planes_resolve(const uint64_t *zbuf, float *VMap, float *RGBD, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab,
+                        float **ParamTab, int plane_lo, int plane_hi, const float *pose_world_to_cam, int N, int M,
+                        const float *calib, int n, int m);
+
 #endif

@@ -240,6 +240,19 @@ class Context:
     def raster_clear(self, zbuf, n, m):
         _chk(self.lib.rgbdslam_raster_clear(self._h, _ptr(zbuf), n, m), "raster_clear")
 
+    # -- prediction from the planes --
+    def planes_draw(self, zbuf, bump_tab, rgb_tab, mask_tab, param_tab, plane_lo, plane_hi, pose_w2c, N_prim, M_prim, n, m,
+                    min_conf=1, thresh=0.1, znear=0.5, zfar=10.0):
+        _chk(self.lib.rgbdslam_planes_draw(self._h, _ptr(zbuf), _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab), _ptr(param_tab),
+                                           plane_lo, plane_hi, _host16(pose_w2c), N_prim, M_prim, C.c_ushort(min_conf),
+                                           C.c_float(thresh), C.c_float(znear), C.c_float(zfar), n, m), "planes_draw")
+
+    def planes_resolve(self, zbuf, vmap, rgbd, bump_tab, rgb_tab, mask_tab, param_tab, plane_lo, plane_hi, pose_w2c, N_prim,
+                       M_prim, n, m, reset=True):
+        _chk(self.lib.rgbdslam_planes_resolve(self._h, _ptr(zbuf), _ptr(vmap), _ptr(rgbd), _ptr(bump_tab), _ptr(rgb_tab),
+                                              _ptr(mask_tab), _ptr(param_tab), plane_lo, plane_hi, _host16(pose_w2c), N_prim,
+                                              M_prim, int(reset), n, m), "planes_resolve")
+
     # -- 16-bit labels (models of more than 255 planes) --
     def update_l16(self, bump_tab, rgb_tab, mask_tab, param_tab, claim_tab, stamp, vmap, rgbd, mask, label16, pose, N_prim,
                    M_prim, n, m, plane_lo=0, plane_hi=0x7FFFFFFF):

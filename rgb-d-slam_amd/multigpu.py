@@ -241,3 +241,24 @@ class PlaneShard:
                                              pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m, self.lo, self.hi)
             self.ctx.vertex_from_bump_batch(self.t_vout, self.t_cout, self.t_kout, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
                                             self.lo, self.hi, self.N, self.N)
+
+
+_SIGN64 = -(1 << 63)
+
+
+def allreduce_min_u64(zbuf):
+    """Merge of the z-buffers that the ranks drew from their own planes (rgbdslam_planes_draw): elementwise UNSIGNED 64-bit
+    minimum over all ranks, in place.  The key is depth bits << 32 | ~triangle id, so the minimum is the nearest surface
+    whichever rank drew it.  torch has no u64 reductions: the sign bit is flipped (monotonic u64 -> i64), MIN, flipped back."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return zbuf
+    z = zbuf.view(torch.int64)
+    z ^= _SIGN64
+    if z.is_cuda and dist.get_backend() == "gloo":
+        h = z.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        z.copy_(h)
+    else:
+        dist.all_reduce(z, op=dist.ReduceOp.MIN)
+    z ^= _SIGN64
+    return zbuf

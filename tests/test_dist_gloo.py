@@ -199,3 +199,30 @@ def test_plane_partitioned_step_with_frame_broadcast_two_ranks():
     assert all(o["same_frame"] and o["owned_ok"] and o["others_untouched"] for o in out)
     assert len(out[0]["labels"]) >= 4 and out[0]["filled"] > 300
     assert out[0]["nbytes"] >= 30 * 60 * 80 + 64
+
+
+# ---- prediction from the planes: z-buffers of disjoint plane ranges merge by an unsigned 64-bit minimum ---------------------
+def _zmerge(rank, world):
+    mg = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m, N, nb = 60, 80, 64, 6
+    orc, synth, calib, s = _scene(n, m)
+    params = synth.tiled_planes(nb, N, res=0.04)        # 4 cm cells: at 60 x 80 a pixel spans ~3 cm, so neighbouring cells fill
+    pose = np.eye(4, dtype=np.float32).T.reshape(-1)
+    label = orc.label_planes_l16(s["v0"], s["n0"], pose, list(params), N, N)
+    mk = lambda shape, dt, v=0: [np.full(shape, v, dt) for _ in range(nb)]
+    b, c, k, cl = mk((N, N, 3), np.uint16), mk((N, N, 3), np.uint8), mk((N, N), np.uint8, 10), mk((N, N), np.uint64)
+    orc.update_l16(b, c, k, list(params), cl, 1, s["v0"], s["rgbd0"], np.full((n, m), 12, np.uint8), label, pose)
+    full = np.full((n, m), 0xFFFFFFFFFFFFFFFF, np.uint64)
+    orc.planes_draw(full, b, c, k, list(params), 0, nb, pose, calib, n, m, min_conf=1)
+    lo, hi = mg.plane_range(rank, world, nb)
+    mine = np.full((n, m), 0xFFFFFFFFFFFFFFFF, np.uint64)
+    orc.planes_draw(mine, b, c, k, list(params), lo, hi, pose, calib, n, m, min_conf=1)
+    merged = mg.allreduce_min_u64(torch.from_numpy(mine.view(np.int64))).numpy().view(np.uint64)
+    return dict(ok=bool(np.array_equal(merged, full)), covered=float((full != 0xFFFFFFFFFFFFFFFF).mean()),
+                partial=bool(not np.array_equal(mine, full)))
+
+
+def test_plane_partitioned_prediction_zbuffer_merge_two_ranks():
+    out = _spawn(_zmerge)
+    assert all(o["ok"] for o in out) and out[0]["covered"] > 0.05
+    assert any(o["partial"] for o in out)               # at least one rank alone did not have the whole picture

@@ -1,0 +1,137 @@
+"""Prediction of the model directly from the Bump images (rgbdslam_planes_draw / _resolve): the reference's plane meshes
+(VertexFromBump + QuadTrim) through the frame rasteriser's rules.  Z-buffer keys and resolved maps bit-exact against the
+oracle; disjoint plane ranges merge by a u64 minimum into exactly the single-launch result (the multi-GPU form); the
+predicted depth agrees with the depth image that was fused."""
+import importlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from test_gpu_kernels import dev, host, same, pose16, _plane_setup, _ptr_table  # noqa: E402
+
+SIGN = -(1 << 63)
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg, synth):
+    c = pkg.Context(0)
+    c.set_calibration_matrix(synth.TUM_CALIB)
+    yield c
+    c.close()
+
+
+def _u64_min(a, b):
+    """elementwise unsigned minimum of two int64-typed u64 images (what an all-reduce MIN does after the sign flip)"""
+    return torch.minimum(a ^ SIGN, b ^ SIGN) ^ SIGN
+
+
+def _w2c(R, t):
+    Rinv = np.linalg.inv(np.asarray(R, np.float64))
+    return pose16(Rinv.astype(np.float32), (-Rinv @ np.asarray(t, np.float64)).astype(np.float32))
+
+
+def test_three_planes_draw_resolve_partition(ctx, orc, pair, synth):
+    n, m, N = 480, 640, 512
+    calib = pair["calib"]
+    eq, params = _plane_setup(synth, N)
+    I16 = pose16(np.eye(3), np.zeros(3))
+    label = orc.seed_labels(pair["v0"], pair["n0"], I16, eq)
+    bumps = [np.zeros((N, N, 3), np.uint16) for _ in range(3)]
+    rgbs = [np.zeros((N, N, 3), np.uint8) for _ in range(3)]
+    masks = [np.full((N, N), 10, np.uint8) for _ in range(3)]
+    claims = [np.zeros((N, N), np.uint64) for _ in range(3)]
+    rng = np.random.default_rng(5)
+    orc.update(bumps, rgbs, masks, params, claims, 1, pair["v0"], pair["rgbd0"], rng.integers(11, 30, (n, m)).astype(np.uint8), label, I16)
+    masks[1][200:210, 200:230] = 1                               # the "locked" value counts as a valid corner (Primitive.cu:135)
+    keep = [dev(x) for lst in (bumps, rgbs, masks, params) for x in lst]   # (tables hold raw pointers)
+    tabs = [_ptr_table(keep[3 * k:3 * k + 3]) for k in range(4)]
+    for P, name in ((I16, "identity"), (_w2c(pair["R1"], pair["t1"] * 3), "moved")):
+        zbuf = torch.empty(n, m, dtype=torch.int64, device="cuda")
+        ctx.raster_clear(zbuf, n, m)
+        ctx.planes_draw(zbuf, tabs[0], tabs[1], tabs[2], tabs[3], 0, 3, P, N, N, n, m)
+        z_ref = np.full((n, m), 0xFFFFFFFFFFFFFFFF, np.uint64)
+        orc.planes_draw(z_ref, bumps, rgbs, masks, params, 0, 3, P, calib, n, m, min_conf=1)
+        same(host(zbuf).view(np.uint64), z_ref)
+        covered = (z_ref != 0xFFFFFFFFFFFFFFFF).mean()
+        assert covered > 0.5, "%s: only %.2f of the view predicted" % (name, covered)
+        # plane ranges drawn apart and merged by the unsigned minimum == one launch
+        za = torch.empty_like(zbuf); zb = torch.empty_like(zbuf)
+        ctx.raster_clear(za, n, m); ctx.raster_clear(zb, n, m)
+        ctx.planes_draw(za, tabs[0], tabs[1], tabs[2], tabs[3], 0, 1, P, N, N, n, m)
+        ctx.planes_draw(zb, tabs[0], tabs[1], tabs[2], tabs[3], 1, 3, P, N, N, n, m)
+        assert torch.equal(_u64_min(za, zb), zbuf)
+        # resolve: every rank writes the pixels its planes won; together == the single call == the oracle
+        v1 = torch.full((n, m, 3), -5.0, device="cuda"); c1 = torch.full((n, m, 4), -5.0, device="cuda")
+        v2 = torch.full((n, m, 3), -5.0, device="cuda"); c2 = torch.full((n, m, 4), -5.0, device="cuda")
+        zc = zbuf.clone()
+        ctx.planes_resolve(zc, v2, c2, tabs[0], tabs[1], tabs[2], tabs[3], 0, 1, P, N, N, n, m, reset=False)
+        ctx.planes_resolve(zc, v2, c2, tabs[0], tabs[1], tabs[2], tabs[3], 1, 3, P, N, N, n, m, reset=False)
+        ctx.planes_resolve(zbuf, v1, c1, tabs[0], tabs[1], tabs[2], tabs[3], 0, 3, P, N, N, n, m, reset=True)
+        assert torch.equal(v1, v2) and torch.equal(c1, c2)
+        assert bool((zbuf == -1).all())                          # left clean for the next frame
+        rv = np.full((n, m, 3), -5.0, np.float32); rc = np.full((n, m, 4), -5.0, np.float32)
+        orc.planes_resolve(z_ref, rv, rc, bumps, rgbs, masks, params, 0, 3, P, calib)
+        same(host(v1), rv)
+        same(host(c1), rc)
+        if name == "identity":
+            # the model was fused from this very view: predicted depth == observed depth up to the codec (0.5 mm) and the
+            # 4 mm cell raster
+            ok = (rv[..., 2] != 0) & (pair["v0"][..., 2] != 0)
+            err = np.abs(rv[..., 2] - pair["v0"][..., 2])[ok]
+            assert ok.mean() > 0.5 and np.percentile(err, 95) < 0.004, (ok.mean(), np.percentile(err, 95))
+            col = np.abs(rc[..., :3] - pair["rgbd0"][..., :3])[ok]
+            assert np.percentile(col, 90) < 0.08
+
+
+def test_256_planes_eight_way_partition_equals_single_launch(ctx, orc, pair, synth):
+    multigpu = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m, N, planes = 480, 640, 512, 256
+    calib = pair["calib"]
+    params = synth.tiled_planes(planes, N)
+    I16 = pose16(np.eye(3), np.zeros(3))
+    label = orc.label_planes_l16(pair["v0"], pair["n0"], I16, list(params), N, N)
+    bump = torch.zeros(planes, N, N, 3, dtype=torch.int16, device="cuda")
+    rgbb = torch.zeros(planes, N, N, 3, dtype=torch.uint8, device="cuda")
+    mask = torch.full((planes, N, N), 10, dtype=torch.uint8, device="cuda")
+    claim = torch.zeros(planes, N, N, dtype=torch.int64, device="cuda")
+    g_param = dev(params)
+    tab = lambda t: torch.tensor([t[k].data_ptr() for k in range(planes)], dtype=torch.int64, device="cuda")
+    t_b, t_c, t_m, t_p, t_k = tab(bump), tab(rgbb), tab(mask), tab(g_param), tab(claim)
+    conf = np.full((n, m), 12, np.uint8)
+    ctx.update_l16(t_b, t_c, t_m, t_p, t_k, 1, dev(pair["v0"]), dev(pair["rgbd0"]), dev(conf), dev(label.view(np.int16)), I16, N, N, n, m)
+    P = _w2c(pair["R1"], pair["t1"] * 2)
+    single = torch.empty(n, m, dtype=torch.int64, device="cuda")
+    ctx.raster_clear(single, n, m)
+    ctx.planes_draw(single, t_b, t_c, t_m, t_p, 0, planes, P, N, N, n, m)
+    merged = torch.full((n, m), -1, dtype=torch.int64, device="cuda")
+    outs_v = torch.full((n, m, 3), -5.0, device="cuda"); outs_c = torch.full((n, m, 4), -5.0, device="cuda")
+    for r in range(8):                                           # what each of eight ranks would draw, then the all-reduce(min)
+        lo, hi = multigpu.plane_range(r, 8, planes)
+        z = torch.empty_like(single)
+        ctx.raster_clear(z, n, m)
+        ctx.planes_draw(z, t_b, t_c, t_m, t_p, lo, hi, P, N, N, n, m)
+        merged = _u64_min(merged, z)
+    assert torch.equal(merged, single)
+    assert float((single != -1).float().mean()) > 0.5
+    for r in range(8):                                           # ... and every rank resolves what its planes won
+        lo, hi = multigpu.plane_range(r, 8, planes)
+        ctx.planes_resolve(merged, outs_v, outs_c, t_b, t_c, t_m, t_p, lo, hi, P, N, N, n, m, reset=False)
+    v1 = torch.full((n, m, 3), -5.0, device="cuda"); c1 = torch.full((n, m, 4), -5.0, device="cuda")
+    ctx.planes_resolve(single, v1, c1, t_b, t_c, t_m, t_p, 0, planes, P, N, N, n, m, reset=False)
+    assert torch.equal(v1, outs_v) and torch.equal(c1, outs_c)
+    # the oracle on the planes the frame touched (all other planes are empty: every quad is rejected)
+    touched = sorted(set(int(x) - 1 for x in np.unique(label) if x > 0))
+    hb = {k: host(bump[k]).view(np.uint16) for k in touched}
+    hc = {k: host(rgbb[k]) for k in touched}
+    hm = {k: host(mask[k]) for k in touched}
+    d3, d1 = np.zeros((1, 1, 3), np.uint16), np.zeros((1, 1), np.uint8)
+    fill = lambda dct, d: [dct.get(k, d) for k in range(planes)]
+    z_ref = np.full((n, m), 0xFFFFFFFFFFFFFFFF, np.uint64)
+    for k in touched:
+        orc.planes_draw(z_ref, fill(hb, d3), fill(hc, d3.astype(np.uint8)), fill(hm, d1), list(params), k, k + 1, P, calib, n, m, min_conf=1,
+                        size=(N, N))
+    same(host(single).view(np.uint64), z_ref)
+    assert max(touched) == 255                                   # ids of the last plane fit the 32-bit triangle id
