@@ -217,9 +217,9 @@ def _zmerge(rank, world):
     lo, hi = mg.plane_range(rank, world, nb)
     mine = np.full((n, m), 0xFFFFFFFFFFFFFFFF, np.uint64)
     orc.planes_draw(mine, b, c, k, list(params), lo, hi, pose, calib, n, m, min_conf=1)
-    merged = mg.allreduce_min_u64(torch.from_numpy(mine.view(np.int64))).numpy().view(np.uint64)
-    return dict(ok=bool(np.array_equal(merged, full)), covered=float((full != 0xFFFFFFFFFFFFFFFF).mean()),
-                partial=bool(not np.array_equal(mine, full)))
+    partial = bool(not np.array_equal(mine, full))
+    merged = mg.allreduce_min_u64(torch.from_numpy(mine.view(np.int64))).numpy().view(np.uint64)      # in place
+    return dict(ok=bool(np.array_equal(merged, full)), covered=float((full != 0xFFFFFFFFFFFFFFFF).mean()), partial=partial)
 
 
 def test_plane_partitioned_prediction_zbuffer_merge_two_ranks():
