@@ -84,6 +84,13 @@ int rgbdslam_compute_normal(rgbdslam_ctx *ctx, float *NMap, const float *VMap, i
 int rgbdslam_intensity_sobel(rgbdslam_ctx *ctx, const float *rgb, float *img, size_t img_pitch,
                              float *gx, size_t gx_pitch, float *gy, size_t gy_pitch, int n, int m);
 
+/* OPTIONAL, default-off stage of OffLineFrame::LoadFrame: the filter the reference carries commented out at Frame.cpp:50-54
+ * (depth.convertTo(CV_32FC1); bilateralFilter(tmp, out, 5, 100.0, 100.0); out.convertTo(CV_16UC1)).  cv::bilateralFilter is
+ * third-party (OpenCV 2.4): restated from its published float algorithm (circular window of radius d/2, reflect-101 border,
+ * 4096-bin interpolated exponential table for the range weights, spanning the full u16 range).  dst != src; radius <= 4. */
+int rgbdslam_bilateral_depth(rgbdslam_ctx *ctx, uint16_t *dst, size_t dst_pitch_bytes, const uint16_t *src,
+                             size_t src_pitch_bytes, int d, double sigma_color, double sigma_space, int n, int m);
+
 /* ---- stage 2+3: ICP normal equations ------------------------------------------------------ */
 /* ICP.cuh:6-7  void AllocBuffers(int n, int m); void FreeBuffers()  (n, m = 8x8-block grid; the
  * scratch here is a fixed 27 x 512 floats, so the arguments only have to be positive) */

@@ -332,6 +332,9 @@ class Slam:
         nb = self._lib.orc_slam_detect_planes(self._h, int(min_size), int(min_normals), _p(eq), _p(ce))
         return eq[:nb], ce[:nb]
 
+    def set_bilateral(self, on):
+        self._lib.orc_slam_set_bilateral(self._h, int(on))
+
     def set_finish(self, enabled=True, first_after=30, period=100, min_size=-1, min_normals=-1):
         """RG::Finish schedule (D1/RG.cpp:149-271)."""
         self._lib.orc_slam_set_finish(self._h, int(enabled), int(first_after), int(period), int(min_size), int(min_normals))
@@ -545,3 +548,11 @@ def planes_resolve(zbuf, vmap, rgbd, bumps, rgbs, masks, params, plane_lo, plane
     N, M = size if size is not None else masks[0].shape
     lib().orc_planes_resolve(_p(zbuf), _p(vmap), _p(rgbd), _ptr_table(bumps), _ptr_table(rgbs), _ptr_table(masks), _ptr_table(params),
                              plane_lo, plane_hi, _p(_f32(pose_w2c)), N, M, _p(_f32(calib)), n, m)
+
+
+def bilateral_depth(depth, d=5, sigma_color=100.0, sigma_space=100.0):
+    n, m = depth.shape
+    src = np.ascontiguousarray(depth, np.uint16)
+    out = np.empty_like(src)
+    lib().orc_bilateral_depth(_p(out), _p(src), C.c_size_t(m), int(d), C.c_double(sigma_color), C.c_double(sigma_space), n, m)
+    return out

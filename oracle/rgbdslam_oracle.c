@@ -579,6 +579,53 @@ int orc_align_gauss_newton(const orc_icp_params *prm, const float *intr,
     return 1;
 }
 
+/* ---- optional stage: the bilateral filter the reference carries commented out (Frame.cpp:50-54) -----------------------
+ * cv::bilateralFilter on the depth converted to float, d = 5, sigmaColor = sigmaSpace = 100, converted back to u16.  OpenCV 2.4
+ * is third-party and absent: restated from its published float algorithm (circular window, reflect-101 border, interpolated
+ * 4096-bin exponential table for the range weights); the table spans the full u16 range, not the image's min..max. */
+static int reflect101_o(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+    return p;
+}
+void orc_bilateral_depth(uint16_t *dst, const uint16_t *src, size_t pitch, int d, double sigma_color, double sigma_space, int n, int m) {
+    if (sigma_color <= 0.0) sigma_color = 1.0;
+    if (sigma_space <= 0.0) sigma_space = 1.0;
+    int radius = d <= 0 ? (int)rint(sigma_space * 1.5) : d / 2;
+    if (radius < 1) radius = 1;
+    const double gcc = -0.5 / (sigma_color * sigma_color), gsc = -0.5 / (sigma_space * sigma_space);
+    const int bins = 4096;
+    const float len = 65535.0f, scale_index = (float)bins / len;
+    float *lut = (float *)malloc(sizeof(float) * (bins + 2));
+    for (int i = 0; i < bins + 2; i++) { double val = (double)i / (double)scale_index; lut[i] = (float)exp(val * val * gcc); }
+    int cnt = 0, dy[81], dx[81];
+    float sw[81];
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+            double r = sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            dy[cnt] = i; dx[cnt] = j; sw[cnt++] = (float)exp(r * r * gsc);
+        }
+    #pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            float val0 = (float)src[(size_t)i * pitch + j], sum = 0.0f, wsum = 0.0f;
+            for (int k = 0; k < cnt; k++) {
+                float val = (float)src[(size_t)reflect101_o(i + dy[k], n) * pitch + reflect101_o(j + dx[k], m)];
+                float alpha = fabsf(val - val0) * scale_index;
+                int idx = (int)floorf(alpha);
+                alpha = alpha - (float)idx;
+                float w = sw[k] * (lut[idx] + alpha * (lut[idx + 1] - lut[idx]));
+                sum = sum + val * w;
+                wsum = wsum + w;
+            }
+            float o = rintf(sum / wsum);
+            o = o < 0.0f ? 0.0f : (o > 65535.0f ? 65535.0f : o);
+            dst[(size_t)i * pitch + j] = (uint16_t)o;
+        }
+    free(lut);
+}
+
 /* ===================================================================================== */
 /* Stage 4: fusion                                                                       */
 /* ===================================================================================== */
@@ -1384,6 +1431,7 @@ struct orc_slam {
     uint32_t stamp;
     float poseR[9], poset[3], poseRPrev[9], posetPrev[3];
     /* RG::Finish schedule (RG.cpp:149-271) */
+    int bilateral;                  /* optional stage of LoadFrame (Frame.cpp:50-54), default off */
     int finish_enabled, finish_first_after, finish_period, finish_min_size, finish_min_normals, first_in, indx, finish_detections;
 };
 
@@ -1506,7 +1554,8 @@ int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr) {
     int n = s->n, m = s->m;
     size_t P = (size_t)n * m;
     /* 1. LoadFrame (Frame.cpp:43-77) */
-    memcpy(s->depth, depth, 2 * P);
+    if (s->bilateral) orc_bilateral_depth(s->depth, depth, m, 5, 100.0, 100.0, n, m);   /* Frame.cpp:50-54, when switched on */
+    else memcpy(s->depth, depth, 2 * P);
     orc_cpy_char3(bgr, 3 * (size_t)m, s->fRGB, n, m);
     orc_vertex_map_kinect(s->fV, s->depth, m, s->calib, n, m);
     orc_compute_normal(s->fN, s->fV, n, m, 1);
@@ -1577,6 +1626,7 @@ int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr) {
     return first ? 2 : 1;
 }
 
+void orc_slam_set_bilateral(orc_slam *s, int on) { s->bilateral = on; }
 void orc_slam_set_finish(orc_slam *s, int enabled, int first_after, int period, int min_size, int min_normals) {
     s->finish_enabled = enabled; s->finish_first_after = first_after; s->finish_period = period;
     if (min_size >= 0) s->finish_min_size = min_size;

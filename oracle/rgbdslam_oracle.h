@@ -152,6 +152,9 @@ void orc_slam_set_planes(orc_slam *s, const float *equations, const float *cente
 int orc_slam_detect_planes(orc_slam *s, int min_size, int min_normals, float *equations_out, float *centers_out);
 /* One display() pass. Returns 1 tracked, 0 lost (model re-seeded), 2 first frame (model seeded). */
 int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr);
+/* optional stage (Frame.cpp:50-54, commented out in the reference): cv::bilateralFilter(depth, 5, 100, 100) before everything */
+void orc_bilateral_depth(uint16_t *dst, const uint16_t *src, size_t pitch, int d, double sigma_color, double sigma_space, int n, int m);
+void orc_slam_set_bilateral(orc_slam *s, int on);
 /* RG::Finish schedule (RG.cpp:149-271), run at the end of every tracked step: first detection when count > first_after (30),
  * re-detection when count % period == 0 (100; 0 = never); min_size / min_normals >= 0 override 5000 / 1000 */
 void orc_slam_set_finish(orc_slam *s, int enabled, int first_after, int period, int min_size, int min_normals);

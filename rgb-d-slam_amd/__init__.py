@@ -104,6 +104,10 @@ class Context:
     def gpu_cpy_char3(self, bgr, pitch, rgb, n, m):
         _chk(self.lib.rgbdslam_gpu_cpy_char3(self._h, _ptr(bgr), C.c_size_t(pitch), _ptr(rgb), n, m), "gpu_cpy_char3")
 
+    def bilateral_depth(self, dst, dst_pitch, src, src_pitch, n, m, d=5, sigma_color=100.0, sigma_space=100.0):
+        _chk(self.lib.rgbdslam_bilateral_depth(self._h, _ptr(dst), C.c_size_t(dst_pitch), _ptr(src), C.c_size_t(src_pitch), int(d),
+                                               C.c_double(sigma_color), C.c_double(sigma_space), n, m), "bilateral_depth")
+
     def compute_normal(self, nmap, vmap, n, m, inverse=True):
         _chk(self.lib.rgbdslam_compute_normal(self._h, _ptr(nmap), _ptr(vmap), n, m, int(inverse)), "compute_normal")
 
@@ -503,6 +507,11 @@ class RG:
         eq, ce = np.zeros((cap, 10), np.float32), np.zeros((cap, 3), np.float32)
         _hchk(self.lib.slamhost_rg_get_planes(self._h, C.c_void_p(eq.ctypes.data), C.c_void_p(ce.ctypes.data), cap), "get_planes")
         return eq[:nb.value], ce[:nb.value]
+
+    def set_bilateral(self, on):
+        """Optional stage of OffLineFrame::LoadFrame, default OFF like in the reference (the call is commented out there,
+        D1/Frame.cpp:50-54): cv::bilateralFilter(depth, 5, 100.0, 100.0) before the vertex map is computed."""
+        _hchk(self.lib.slamhost_rg_set_bilateral(self._h, int(on)), "set_bilateral")
 
     def set_finish(self, enabled=True, first_after=30, period=100, save_dir=None, min_size=-1, min_normals=-1):
         """RG::Finish schedule (D1/RG.cpp:149-271): first plane detection when _count > first_after, then every `period`

@@ -55,6 +55,7 @@ struct rgbdslam_ctx {
     unsigned int *xchg_peer[8];    // [xchg_rank] = this rank's own block; the others are IPC mappings of the peers' blocks
     int xchg_world, xchg_rank;
     unsigned int xchg_seq;         // advances once per exchanged iteration, in lockstep on every rank
+    float *bil_lut; double bil_sigma_color;   // rgbdslam_bilateral_depth: colour-weight table (device) and the sigma it was built for
     // compat.hip: work buffers behind the reference-shaped Update_cu / Segment_cu / Overlap_cu (allocated on first use)
     uint64_t *claim_slab[RGBDSLAM_COMPAT_MAX_PLANES];   // one u64 claim word per Bump cell and plane
     uint64_t **claim_tab_dev;                           // device copy of claim_slab

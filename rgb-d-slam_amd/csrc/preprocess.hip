@@ -2,6 +2,7 @@
 // per-pixel model maintenance kernels of stage 4/5 (merge, vertex-from-depth, model seeding).
 // Lanes run along image columns so every row segment is one coalesced burst.
 #include "device_fns.hpp"
+#include <math.h>
 
 // ---- D1/Kernel.cu:33-52 VertexMapKinectKernel ------------------------------------------------
 __global__ void k_vertex_map_kinect(float *__restrict__ VMap, const uint16_t *__restrict__ depth,
@@ -120,6 +121,47 @@ __global__ void k_init_mask(uint8_t *__restrict__ mask, const float *__restrict_
     mask[idx] = (RGBD[4 * idx + 3] == 0.0f) ? 10 : 11;
 }
 
+// ---- optional, default-OFF stage of OffLineFrame::LoadFrame: the bilateral filter the reference has commented out ---------
+// D1/Frame.cpp:50-54:  depth.convertTo(tmp, CV_32FC1); bilateralFilter(tmp, out, 5, 100.0, 100.0); out.convertTo(depth, CV_16UC1)
+// cv::bilateralFilter is third-party (OpenCV 2.4, version unpinned): restated from its published float algorithm -- circular
+// window of radius d/2, reflect-101 border, spatial weights exp(-r^2 / 2 sigma_s^2), colour weights from a 4096-bin
+// exponential table with linear interpolation -- with ONE stated difference: the table spans the full u16 range instead of
+// the image's own min..max (no reduction pass).  Both tables are computed on the host in double, so the kernel and the
+// oracle only multiply and add: bit-exact.  LDS tile of the depth samples with a `radius` halo.
+#define BIL_MAX_RADIUS 4
+#define BIL_LUT_BINS 4096
+struct BilTaps { int count; signed char dy[81], dx[81]; float w[81]; float scale_index; int radius; };
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_bilateral_depth(uint16_t *__restrict__ dst, size_t dpitch, const uint16_t *__restrict__ src, size_t spitch,
+                       const float *__restrict__ lut, BilTaps T, int n, int m) {
+    __shared__ float tile[TILE_H + 2 * BIL_MAX_RADIUS][TILE_W + 2 * BIL_MAX_RADIUS];
+    const int R = T.radius, j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    const int tw = TILE_W + 2 * R, th = TILE_H + 2 * R;
+    for (int e = threadIdx.y * TILE_W + threadIdx.x; e < tw * th; e += TILE_W * TILE_H) {
+        const int r = e / tw, c = e % tw;
+        const int ii = reflect101(min(i0 + r - R, n - 1 + R), n), jj = reflect101(min(j0 + c - R, m - 1 + R), m);
+        tile[r][c] = (float)((const uint16_t *)((const char *)src + (size_t)ii * spitch))[jj];
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const float val0 = tile[threadIdx.y + R][threadIdx.x + R];
+    float sum = 0.0f, wsum = 0.0f;
+    for (int k = 0; k < T.count; k++) {
+        const float val = tile[threadIdx.y + R + T.dy[k]][threadIdx.x + R + T.dx[k]];
+        float alpha = __builtin_fabsf(val - val0) * T.scale_index;
+        const int idx = (int)__builtin_floorf(alpha);
+        alpha = alpha - (float)idx;
+        const float l0 = lut[idx], l1 = lut[idx + 1];
+        const float w = T.w[k] * (l0 + alpha * (l1 - l0));
+        sum = sum + val * w;
+        wsum = wsum + w;
+    }
+    float o = __builtin_rintf(sum / wsum);                     // convertTo(CV_16UC1): cvRound + saturate
+    o = o < 0.0f ? 0.0f : (o > 65535.0f ? 65535.0f : o);
+    ((uint16_t *)((char *)dst + (size_t)i * dpitch))[j] = (uint16_t)o;
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -187,6 +229,45 @@ extern "C" int rgbdslam_init_mask(rgbdslam_ctx *ctx, uint8_t *mask, const float 
     CHECK_CTX(ctx); CHECK_DIM(n, m);
     if (!mask || !RGBD) return RGBDSLAM_E_ARG;
     KLAUNCH(ctx, k_init_mask, grid2d(n, m), block2d(), mask, RGBD, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// cv::bilateralFilter(depth as f32, d, sigmaColor, sigmaSpace) + conversion back to u16 (D1/Frame.cpp:50-54, commented out in the
+// reference: an OPTIONAL stage, off unless the caller asks for it).  dst != src.
+extern "C" int rgbdslam_bilateral_depth(rgbdslam_ctx *ctx, uint16_t *dst, size_t dst_pitch, const uint16_t *src, size_t src_pitch, int d,
+                                        double sigma_color, double sigma_space, int n, int m) {
+    CHECK_CTX(ctx); CHECK_DIM(n, m);
+    if (!dst || !src || dst == src || dst_pitch < 2 * (size_t)m || src_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
+    if (sigma_color <= 0.0) sigma_color = 1.0;                 // OpenCV's own defaults for non-positive sigmas
+    if (sigma_space <= 0.0) sigma_space = 1.0;
+    int radius = d <= 0 ? (int)__builtin_rint(sigma_space * 1.5) : d / 2;
+    if (radius < 1) radius = 1;
+    if (radius > BIL_MAX_RADIUS) return RGBDSLAM_E_LIMIT;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->bil_lut) HIP_TRY(hipMalloc((void **)&ctx->bil_lut, sizeof(float) * (BIL_LUT_BINS + 2)));
+    const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color), gauss_space_coeff = -0.5 / (sigma_space * sigma_space);
+    const float len = 65535.0f, scale_index = (float)BIL_LUT_BINS / len;
+    if (ctx->bil_sigma_color != sigma_color) {
+        float host_lut[BIL_LUT_BINS + 2];
+        for (int i = 0; i < BIL_LUT_BINS + 2; i++) {
+            const double val = (double)i / (double)scale_index;
+            host_lut[i] = (float)exp(val * val * gauss_color_coeff);
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->bil_lut, host_lut, sizeof(host_lut), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));            // host_lut is a local
+        ctx->bil_sigma_color = sigma_color;
+    }
+    BilTaps T;
+    T.count = 0; T.radius = radius; T.scale_index = scale_index;
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+            const double r = sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            T.dy[T.count] = (signed char)i; T.dx[T.count] = (signed char)j;
+            T.w[T.count++] = (float)exp(r * r * gauss_space_coeff);
+        }
+    KLAUNCH(ctx, k_bilateral_depth, grid2d(n, m), block2d(), dst, dst_pitch, src, src_pitch, ctx->bil_lut, T, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -273,6 +273,13 @@ void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
     hipStream_t main = ctx_stream(_ctx);
     if (_load_stream) check(rgbdslam_set_stream(_ctx, _load_stream), "set_stream");
     int rc;
+    if (_bilateral) {                                                               // Frame.cpp:50-54 (optional stage)
+        if (_depth_filtered[_cur].count != (size_t)_n * _m) _depth_filtered[_cur].alloc((size_t)_n * _m, false);
+        rc = rgbdslam_bilateral_depth(_ctx, _depth_filtered[_cur].p, 2 * (size_t)_m, _depth_cur[_cur], _depth_pitch[_cur], 5, 100.0, 100.0, _n, _m);
+        if (rc) { if (_load_stream) (void)rgbdslam_set_stream(_ctx, main); check(rc, "bilateral_depth"); }
+        _depth_cur[_cur] = _depth_filtered[_cur].p;
+        _depth_pitch[_cur] = 2 * (size_t)_m;
+    }
     if (_gradients) {
         rc = rgbdslam_frame_preprocess(_ctx, _depth_cur[_cur], _depth_pitch[_cur], bgr, bgr_pitch, getVMap(), getNMap(), getRGB(), getGx(),
                                        4 * (size_t)_m, getGy(), 4 * (size_t)_m, _n, _m);
@@ -993,7 +1000,7 @@ int RG::StepAsync() {
     if (!ov) {
         // GP-demo.cpp:260; when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides along:
         // every reader of this frame's maps has been enqueued, so the same buffers take the next frame's
-        if (claim_in_merge && _next_hint.valid && !ovl && _frame->has_gradients())
+        if (claim_in_merge && _next_hint.valid && !ovl && _frame->has_gradients() && !_frame->bilateral())
             _graph->ApplyTrackedAndPreprocess(_predicted_frame, _pb_dev, upd, _frame, _next_hint.depth, _next_hint.depth_pitch,
                                               _next_hint.bgr, _next_hint.bgr_pitch);
         else if (claim_in_merge) _graph->ApplyTracked(_predicted_frame, _pb_dev, upd);
@@ -1432,6 +1439,12 @@ int slamhost_rg_detect_planes(void *rg, int min_size, int min_normals, int *nb) 
 }
 // RG::Finish schedule: enabled, first detection when _count > first_after, dump + re-detection when _count % period == 0
 // (period 0 = never); save_dir NULL / "" = no dump; min_size / min_normals >= 0 override MIN_SIZE_PLAN / 1000 (small images)
+// optional bilateral stage of OffLineFrame::LoadFrame (Frame.cpp:50-54, commented out in the reference): default off
+int slamhost_rg_set_bilateral(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    ((RG *)rg)->_frame->EnableBilateral(on != 0);
+    return 0;
+}
 int slamhost_rg_set_finish(void *rg, int enabled, int first_after, int period, const char *save_dir, int min_size, int min_normals) {
     if (!rg || first_after < 0 || period < 0) return RGBDSLAM_E_ARG;
     RG *r = (RG *)rg;

@@ -110,6 +110,10 @@ public:
     // fused pipeline: with gradients enabled, LoadFrame* runs rgbdslam_frame_preprocess (one kernel for
     // Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
     void EnableGradients(bool on);
+    // OPTIONAL stage, off by default: cv::bilateralFilter(depth, 5, 100.0, 100.0) before everything else -- the lines the
+    // reference carries commented out (Frame.cpp:50-54).  The filtered image replaces the depth for the whole frame (Merge too).
+    void EnableBilateral(bool on) { _bilateral = on; }
+    bool bilateral() const { return _bilateral; }
     bool has_gradients() const { return _gradients; }
     float *getGx() { return _Gx[_cur].p; }
     float *getGy() { return _Gy[_cur].p; }
@@ -130,7 +134,9 @@ private:
     DevBuf<float> _Gx[2], _Gy[2];
     const uint16_t *_depth_cur[2] = {nullptr, nullptr};
     size_t _depth_pitch[2] = {0, 0};
-    bool _gradients = false;
+    bool _gradients = false, _bilateral = false;
+    DevBuf<uint16_t> _depth_filtered[2];
+    void filter_depth();
     hipStream_t _load_stream = nullptr;
     hipEvent_t _ready[2] = {nullptr, nullptr}, _free[2] = {nullptr, nullptr};
     bool _free_recorded[2] = {false, false};

@@ -197,3 +197,65 @@ def test_reference_shaped_update_and_segment(ctx, orc, pair, synth):
     g_h2 = dev(h2)
     ctx.segment_cu(g_h2, dev(v2), dev(n2map), I16, dev(eq), 3, n2, m2)
     same(host(g_h2), orc.segment(h2, v2, n2map, I16, eq))
+
+
+# ---- the optional, default-off bilateral stage of OffLineFrame::LoadFrame (D1/Frame.cpp:50-54) ---------------------------
+@pytest.mark.parametrize("shape,pitch_extra", [((480, 640), 0), ((37, 53), 22), ((5, 130), 2)])
+def test_bilateral_depth_kernel(ctx, orc, synth, shape, pitch_extra):
+    n, m = shape
+    calib = synth.calib_for(n, m)
+    rng = np.random.default_rng(6)
+    d, _ = synth.render(np.eye(3), np.zeros(3), n, m, calib, noise_sigma=0.002, rng=rng)
+    d[::9, ::7] = 0                                            # holes
+    d[n // 2:, m // 2:] += 900                                 # a depth step of 18 cm: must survive the filter
+    pitch = m + pitch_extra
+    src = np.zeros((n, pitch), np.uint16)
+    src[:, :m] = d
+    dst = torch.full((n, pitch), 7, dtype=torch.int16, device="cuda")
+    ctx.bilateral_depth(dst, 2 * pitch, dev(src), 2 * pitch, n, m)
+    got = host(dst).view(np.uint16)
+    want = orc.bilateral_depth(d)
+    same(got[:, :m], want)
+    assert (got[:, m:] == 7).all()
+    if n >= 37:
+        # edge preserving: the two sides of the step stay apart; smoothing: the noise on the planes shrinks
+        valid = (d > 0)
+        a, b = want[n // 2 - 1, 5:m // 2 - 5].astype(np.int64), want[n // 2 + 1, m // 2 + 5:m - 5].astype(np.int64)
+        assert abs(int(np.median(b)) - int(np.median(a))) > 500
+        clean, _ = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+        sel = valid.copy()
+        sel[:2] = sel[-2:] = False; sel[:, :2] = sel[:, -2:] = False
+        sel[n // 2 - 3:, m // 2 - 3:] = False                  # keep away from the synthetic step
+        sel &= np.roll(valid, 1, 0) & np.roll(valid, -1, 0) & np.roll(valid, 1, 1) & np.roll(valid, -1, 1)
+        e_in = np.abs(d.astype(np.int64) - clean)[sel].mean()
+        e_out = np.abs(want.astype(np.int64) - clean)[sel].mean()
+        if n >= 480:                                           # (at 37 x 53 the planes' own slope per pixel exceeds the noise)
+            assert e_out < 0.8 * e_in, (e_in, e_out)
+
+
+def test_bilateral_stage_in_the_loop_default_off(pkg, orc, synth):
+    from test_gpu_slam_loop import same as same_named
+    n, m = 120, 160
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(5, n, m, calib, noise_sigma=0.002)
+    runs = {}
+    for on in (False, True):
+        ref = orc.Slam(n, m, calib, N_prim=256, M_prim=256)
+        rg = pkg.RG(n, m, calib, N_prim=256, M_prim=256)
+        if on:
+            ref.set_bilateral(True)
+            rg.set_bilateral(True)
+        for f, (d, c) in enumerate(seq):
+            st = ref.step(d, c)
+            rg.load_frame(d, c)
+            assert rg.step() == st
+            R, t = rg.pose()
+            Rr, tr = ref.pose()
+            same_named(np.array(R, np.float32), Rr, "poseR %d" % f)
+            same_named(np.array(t, np.float32), tr, "poset %d" % f)
+        for name in ("VMap", "NMap", "RGBD", "Mask", "frame.VMap", "frame.NMap"):
+            same_named(rg.buffer(name), ref.buffer(name), name)
+        runs[on] = rg.buffer("frame.VMap").copy()
+        rg.close()
+        ref.close()
+    assert not np.array_equal(runs[False], runs[True])         # the stage does something when asked for, nothing by default
