@@ -380,10 +380,13 @@ __global__ void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *
         const F3 q = xf_dir(P.v, nl);
         for (int k = 0; k < nb; k++) {                  // plane parameters through wave-uniform addresses
             const float *Q = ParamTab[k];
-            float ea = (q.x * Q[0] + q.y * Q[1]) + q.z * Q[2];
+            // the two cheap tests first: the cell geometry (two f64 divisions) only for planes whose equation fits -- the
+            // same three conditions as the oracle's, evaluated lazily
+            const float ea = (q.x * Q[0] + q.y * Q[1]) + q.z * Q[2];
+            const float err = ((p.x * Q[0] + p.y * Q[1]) + p.z * Q[2]) - Q[3];
+            if (__builtin_fabsf(err) > epsilon || ea < alpha) continue;
             UpdCell u;
-            const bool inside = update_cell(p, Q, N_prim, M_prim, u);
-            if (__builtin_fabsf(u.err) > epsilon || ea < alpha || !inside) continue;
+            if (!update_cell(p, Q, N_prim, M_prim, u)) continue;
             res = (uint16_t)(k + 1);
             break;
         }

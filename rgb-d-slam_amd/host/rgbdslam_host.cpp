@@ -1221,7 +1221,9 @@ int slamhost_rg_step_async(void *rg) {
     return 0;
 }
 // Runs `count` display() passes over device-resident frames (depth_dev[k], bgr_dev[k]); returns
-// the number of tracked frames in *tracked.  One host sync per frame (the pose read), no other.
+// the number of tracked frames in *tracked.  Fused pipeline: the whole sequence is enqueued without a host wait and
+// synchronised once at the end (a frame on which RG::Finish runs a detection also waits, by design); unfused pipeline:
+// one host sync per frame (the pose read).
 int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, const uint8_t *const *bgr_dev, int count,
                                     size_t depth_pitch, size_t bgr_pitch, int *tracked) {
     if (!rg || !depth_dev || !bgr_dev || count < 0) return RGBDSLAM_E_ARG;

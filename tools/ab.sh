@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of library variants on one box: tools/ab.sh "<bench args>" A B ...
+# variants/<name>/librgbdslam_hip.so are builds of other revisions / flags made by tools/make_variant.sh NAME [GIT_REV]
+# (git-ignored scratch, shipped to the box by gpurun; the working library is restored at the end).
 args="$1"; shift
 for rep in 1 2; do
 for v in "$@"; do
