@@ -22,7 +22,7 @@ struct IcpRow { float g[7]; float c[7]; };
 // D1/ICP.cu:72-146 searchGauss + 164-205 row construction, split so that every memory access of a
 // stage is issued before anything waits on it (the kernel is a chain of dependent memory round
 // trips; the arithmetic and its order are untouched).
-struct IcpModelPx { F3 np, vp; float4 cp; };
+struct IcpModelPx { F3 np, vp; float ip; };   // ip = intensity of the model pixel (ICP.cu:100), the only use of its colour
 struct IcpCurrPx { F3 nc, s, cc; float gx, gy; };
 struct IcpProj { float d0, d1, d2, n0, n1, n2, az; int pu, pv; size_t pidx; };
 
@@ -31,7 +31,9 @@ __device__ __forceinline__ IcpModelPx icp_load_model(size_t indx, const float *_
     IcpModelPx mp;
     mp.np = ld3(NMap_prev, indx);
     mp.vp = ld3(VMap_prev, indx);
-    mp.cp = *(const float4 *)(RGBD_prev + 4 * indx);
+    const float4 cp = *(const float4 *)(RGBD_prev + 4 * indx);
+    // (float)((double)x / 3.0) == x / 3.0f for float x: double rounding is innocuous for division (53 >= 2*24 + 2)
+    mp.ip = ((cp.x + cp.y) + cp.z) / 3.0f;                                       // ICP.cu:100
     return mp;
 }
 __device__ __forceinline__ IcpProj icp_project(const IcpModelPx &mp, const float *R, const float *t, const float *intr, int n, int m) {
@@ -71,27 +73,27 @@ __device__ __forceinline__ void icp_pin_gather(IcpCurrPx &c) {
                  "+v"(c.cc.z), "+v"(c.gx), "+v"(c.gy));
 }
 
-// Returns false -> zero rows.
+// Returns false -> o untouched (the caller passes zeroed rows and needs no copy).  The four rejection tests of
+// searchGauss are evaluated side by side and the rows sit behind ONE branch: as a cascade of early exits the compiler
+// re-materialised the fourteen zeros at every nesting level (5 x 14 moves per pixel), and the exits never save anything
+// unless all 64 pixels of a block fail the same test.
 __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr, const IcpCurrPx &cu, const float *intr,
-                                         float distThres, float angleThres, IcpRow &o, int &proj) {
-    if (is_zero3(mp.np)) return false;
-    const float4 cp = mp.cp;
+                                         float distThres, float angleThres, bool inside, IcpRow &o, int &proj) {
     const float d0 = pr.d0, d1 = pr.d1, d2 = pr.d2, n0 = pr.n0, n1 = pr.n1, n2 = pr.n2, az = pr.az;
     const size_t pidx = pr.pidx;
-    // (float)((double)x / 3.0) == x / 3.0f for float x: double rounding is innocuous for division (53 >= 2*24 + 2)
-    float i_prev = ((cp.x + cp.y) + cp.z) / 3.0f;                               // ICP.cu:100
-
-    F3 nc = cu.nc;
-    if (is_zero3(nc)) return false;
-    F3 s = cu.s;
+    const float i_prev = mp.ip;
+    const F3 nc = cu.nc;
+    const F3 s = cu.s;
     float ex = d0 - s.x, ey = d1 - s.y, ez = d2 - s.z;
     float dist = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
-    if (dist > distThres) return false;
     float x0 = nc.y * n2 - nc.z * n1;
     float x1 = (-nc.x) * n2 + nc.z * n0;
     float x2 = nc.x * n1 - nc.y * n0;
     float ang = __builtin_sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
-    if (ang > angleThres) return false;
+    // ICP.cu:96-131: zero model normal, zero current normal, distance, angle (a NaN passes both comparisons, as there)
+    // and the sample position beyond the image (ICP.cu:222)
+    const bool reject = (int)!inside | (int)is_zero3(mp.np) | (int)is_zero3(nc) | (int)(dist > distThres) | (int)(ang > angleThres);
+    if (reject) return false;
 
     F3 cc = cu.cc;
     float i_curr = ((cc.x + cc.y) + cc.z) / 3.0f;
@@ -187,7 +189,10 @@ __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
 #pragma unroll
     for (int k = 0; k < 27; k++) x[k] = add_shl<2>(x[k]);
 #pragma unroll
-    for (int k = 0; k < 27; k++) x[k] = add_shl<1>(x[k]);
+    for (int k = 0; k < 27; k++) {
+        x[k] = add_shl<1>(x[k]);
+        asm volatile("" : "+v"(x[k]));                          // or the add is sunk into the branch below and its DPP operand becomes a separate move
+    }
     if (row_head) {
 #pragma unroll
         for (int k = 0; k < 27; k++) tr[k * 8 + r] = x[k];
@@ -297,7 +302,7 @@ struct IcpShared {
 // loads could be served from a stale scalar or vector L1 line), and the tail publishes the next step.
 // persistent loop: the model pixels a wave samples in its first two rounds are the same for every iteration of a
 // level (only the pose changes), so they stay in registers from one step to the next
-struct IcpModelCache { IcpModelPx r0, r1; int lvl; };
+struct IcpModelCache { IcpModelPx r0, r1; int lvl; bool in0, in1; };   // in*: the sample lies inside the image (locate)
 // Line of the chain buffer that holds workgroup t's sums: the 32 workgroups c = 16j + 2v + h that wave v of the tail
 // folds (j = 0..15, h = 0..1) are stored back to back, in the order (j, h).
 __device__ __forceinline__ int icp_chain_line(int t) { return ((t >> 1) & 7) * 32 + ((t >> 4) << 1) + (t & 1); }
@@ -363,7 +368,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane == 0) icp_begin_step(&sst, spose, a.intr4);   // RG.cpp:832-835,851-852
+                if (lane == 0) icp_begin_step(&sst, spose, LOOP ? sst.intr : a.intr4);   // RG.cpp:832-835,851-852 (the loop's prologue has stored the intrinsics)
             }
         } else {
             if (lane < 9) sst.Rcurr[lane] = a.R[lane];
@@ -385,10 +390,14 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     };
     if (LOOP) {
         if (mc.lvl != a.lvl) {                        // first step of a level: both rounds' pixels are requested at once
-            if (wv + ICP_CHAIN_WAVES < chain_len) { locate(wv + ICP_CHAIN_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
-            if (active) { locate(k); mc.r0 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+            mc.in0 = false; mc.in1 = false;
+            if (wv + ICP_CHAIN_WAVES < chain_len) { locate(wv + ICP_CHAIN_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); mc.in1 = inside; }
+            if (active) { locate(k); mc.r0 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); mc.in0 = inside; }
             mc.lvl = a.lvl;
-        } else if (active) locate(k);
+        }
+        // later steps of the level: neither the block's position (two integer divisions) nor its model sample is recomputed
+        // (idx is only needed for the correspondence map, which the persistent loop does not write)
+        inside = mc.in0;
         mp = mc.r0;
     } else if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
     __syncthreads();
@@ -400,37 +409,58 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         return;
     }
 
+    // The pose and the intrinsics of this step, held in VECTOR registers: left to itself the compiler moves these sixteen
+    // uniform LDS values to scalar registers, runs out of those (the loop's arguments fill them) and re-reads each from
+    // a spill lane once per use -- two v_readlane per value per round.
+    float Rc[9], tc3[3], in4[4];
+#pragma unroll
+    for (int z = 0; z < 9; z++) { Rc[z] = sst.Rcurr[z]; asm volatile("" : "+v"(Rc[z])); }
+#pragma unroll
+    for (int z = 0; z < 3; z++) { tc3[z] = sst.tcurr[z]; asm volatile("" : "+v"(tc3[z])); }
+#pragma unroll
+    for (int z = 0; z < 4; z++) { in4[z] = sst.intr[z]; asm volatile("" : "+v"(in4[z])); }
+
     float acc = 0.0f;                                 // wave 0, lanes 0..26: running chain sum (ICP.cu:56-58)
     for (int r = 0; r < rounds; r++) {
         if (r > 0) {
             k = r * ICP_CHAIN_WAVES + wv;
             active = k < chain_len;
             if (active) {
-                locate(k);
-                if (LOOP && r == 1) mp = mc.r1;
-                else mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev);
+                if (LOOP && r == 1) { mp = mc.r1; inside = mc.in1; }
+                else { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
             }
         }
         if (active) {
             IcpRow q;
 #pragma unroll
             for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
-            IcpProj pr = icp_project(mp, sst.Rcurr, sst.tcurr, sst.intr, a.n, a.m);
+            IcpProj pr = icp_project(mp, Rc, tc3, in4, a.n, a.m);
             IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
             icp_pin_gather(cu);
-            if (inside) {
-                int proj = -1;
-                IcpRow o;
-                bool ok = icp_rows(mp, pr, cu, sst.intr, a.distThres, a.angleThres, o, proj);
-                if (ok) q = o;
-                if (a.corr) a.corr[idx] = ok ? proj : -1;
-            }
+            int proj = -1;
+            const bool ok = icp_rows(mp, pr, cu, in4, a.distThres, a.angleThres, inside, q, proj);
+            if (!LOOP && a.corr && inside) a.corr[idx] = ok ? proj : -1;
+            // the 27 products of ICP.cu:229 two at a time (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations per element,
+            // half the instructions): row kk times the aligned pairs (0,1) (2,3) (4,5) (6,-) that reach l >= kk
             float v[27];
-            int term = 0;
+            {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 G[4], C[4];
 #pragma unroll
-            for (int kk = 0; kk < 6; kk++)
+                for (int z = 0; z < 3; z++) { G[z] = f2{q.g[2 * z], q.g[2 * z + 1]}; C[z] = f2{q.c[2 * z], q.c[2 * z + 1]}; }
+                G[3] = f2{q.g[6], q.g[6]}; C[3] = f2{q.c[6], q.c[6]};
+                int term = 0;
 #pragma unroll
-                for (int l = kk; l < 7; l++) v[term++] = q.g[kk] * q.g[l] + q.c[kk] * q.c[l];   // ICP.cu:229
+                for (int kk = 0; kk < 6; kk++) {
+                    const f2 gk = f2{q.g[kk], q.g[kk]}, ck = f2{q.c[kk], q.c[kk]};
+#pragma unroll
+                    for (int pi = kk / 2; pi < 4; pi++) {
+                        const f2 pr2 = gk * G[pi] + ck * C[pi];
+                        if (2 * pi >= kk) v[term++] = pr2.x;
+                        if (2 * pi + 1 <= 6) v[term++] = pr2.y;
+                    }
+                }
+            }
             float sum = fold27(v, lane, tr[wave]);
             if (lane < 27) part[wave][lane] = sum;
         }
@@ -603,7 +633,10 @@ void k_icp_iter(IcpIterArgs a) {
 // waiting workgroup gives up after timeout_ticks so that every wave reaches an exit even if that
 // assumption is broken by another process sharing the device.
 // steps are numbered through the levels, coarse to fine; level k owns [start, start + max_iter + 2)
-struct IcpLoopLevel { int start, grid_rows, grid_cols, lvl, max_iter; };
+// packed (two scalar registers per level instead of five -- the loop is short of them): w0 = start | max_iter << 16 | lvl << 28,
+// w1 = grid_rows | grid_cols << 16
+struct IcpLoopLevel { unsigned int w0, w1; };
+#define ICP_LV_UNUSED 0xffffu
 // The argument block is kept small on purpose: every field stays in a scalar register for the whole
 // loop, and what does not fit is spilled into vector registers and scratch memory.  The five ICP work
 // buffers are therefore one allocation with fixed offsets, and pose_state / status come from pb.
@@ -625,7 +658,7 @@ struct IcpLoopArgs {
     float distThres, angleThres, thr_alpha, thr_tr;
     int n, m;
     float intr4[4];
-    IcpLoopLevel lv[3];                              // unused entries: start = INT_MAX
+    IcpLoopLevel lv[3];                              // unused entries: start = ICP_LV_UNUSED
     int nsteps;
     unsigned int epoch_base;
     int timeout_ticks;
@@ -656,9 +689,10 @@ void k_icp_loop(IcpLoopArgs L) {
         // form from them out of the loop and then spills those registers to scratch memory
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const bool in2 = s >= L.lv[2].start, in1 = s >= L.lv[1].start;
-#define ICP_LV(f) (in2 ? L.lv[2].f : (in1 ? L.lv[1].f : L.lv[0].f))
-        const int grid_rows = ICP_LV(grid_rows), grid_cols = ICP_LV(grid_cols);
+        const bool in2 = s >= (int)(L.lv[2].w0 & 0xffffu), in1 = s >= (int)(L.lv[1].w0 & 0xffffu);
+        const unsigned int lw0 = in2 ? L.lv[2].w0 : (in1 ? L.lv[1].w0 : L.lv[0].w0);
+        const unsigned int lw1 = in2 ? L.lv[2].w1 : (in1 ? L.lv[1].w1 : L.lv[0].w1);
+        const int grid_rows = (int)(lw1 & 0xffffu), grid_cols = (int)(lw1 >> 16);
         const int nchain = min(grid_rows * grid_cols, ICP_CHAINS);
         if (t < min(nchain, ICP_WGS)) {
             IcpIterArgs a;
@@ -670,27 +704,24 @@ void k_icp_loop(IcpLoopArgs L) {
             a.VMap_prev = L.VMap_prev; a.NMap_prev = L.NMap_prev; a.RGBD_prev = L.RGBD_prev;
             a.distThres = L.distThres; a.angleThres = L.angleThres;
             a.n = L.n; a.m = L.m;
-            a.lvl = ICP_LV(lvl); a.max_iter = ICP_LV(max_iter);
+            a.lvl = (int)(lw0 >> 28); a.max_iter = (int)((lw0 >> 16) & 0xfffu);
             a.fact = 1 << a.lvl; a.grid_rows = grid_rows; a.grid_cols = grid_cols;
             a.br_lo = 0; a.rows_local = grid_rows; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
             a.chains = (float *)(L.block + ICP_OFF_CHAINS);
             a.sums = (float *)(L.block + ICP_OFF_OUT); a.corr = nullptr; a.seq = L.epoch_base + (unsigned int)s + 1u;
             a.state = (IcpState *)(L.block + ICP_OFF_STATE); a.pose_state = L.pb->pose_state;
             a.do_solve = 1;
-            const int start = ICP_LV(start);
+            const int start = (int)(lw0 & 0xffffu);
             a.iter = s - start;
             a.thr_alpha = L.thr_alpha; a.thr_tr = L.thr_tr; a.trace = nullptr; a.timing = nullptr;
 #ifdef ICP_LOOP_TIMING
             if (L.timing) a.timing = L.timing + 8 * s;
 #endif
             a.first_launch = (s == 0); a.final_launch = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) a.intr4[k] = L.intr4[k];
             a.pose_state_rw = L.pb->pose_state; a.status = L.pb->status; a.pb = L.pb; a.history = L.history;
             a.frame_index = L.frame_index;
             icp_iter_body<true>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps, CHECK}, tid, t, mc);
         }
-#undef ICP_LV
         __syncthreads();                               // every thread is done with S
         if (tid < 64) {                                // wave 0 polls the published line, one word per lane
             const long long t0 = wall_clock64();
@@ -1349,11 +1380,12 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
             if (prm->max_iter[lvl] < 0 || prm->max_iter[lvl] > 1000) return RGBDSLAM_E_ARG;
             const int gr = div_up(n / f, 8), gc = div_up(m / f, 8);   // D1/ICP.cu:260-261
             if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
-            IcpLoopLevel &lv = L.lv[nl];
-            lv.start = ns; lv.grid_rows = gr; lv.grid_cols = gc; lv.lvl = lvl; lv.max_iter = prm->max_iter[lvl];
+            if (gr > 0xffff || gc > 0xffff || lvl > 3) return RGBDSLAM_E_ARG;
+            L.lv[nl].w0 = (unsigned int)ns | ((unsigned int)prm->max_iter[lvl] << 16) | ((unsigned int)lvl << 28);
+            L.lv[nl].w1 = (unsigned int)gr | ((unsigned int)gc << 16);
             ns += prm->max_iter[lvl] + 2;                      // iter = 0 .. max_iter+1 (RG.cpp:889)
         }
-        for (int k = nl; k < 3; k++) { L.lv[k] = L.lv[0]; L.lv[k].start = 0x7fffffff; }
+        for (int k = nl; k < 3; k++) { L.lv[k] = L.lv[0]; L.lv[k].w0 |= ICP_LV_UNUSED; }
         if (gxp > 0xffffffffu || gyp > 0xffffffffu) return RGBDSLAM_E_ARG;
         L.VMap = VMap; L.NMap = NMap; L.RGB = RGB; L.Gx = Gx; L.Gy = Gy; L.gxp = (unsigned int)gxp; L.gyp = (unsigned int)gyp;
         L.VMap_prev = VMap_prev; L.NMap_prev = NMap_prev; L.RGBD_prev = RGB_prev;
