@@ -93,17 +93,18 @@ static inline dim3 grid2d(int n, int m) { return dim3((m + TILE_W - 1) / TILE_W,
 static inline dim3 block2d() { return dim3(TILE_W, TILE_H); }
 
 // CUDA __float2int_rn / __float2int_rd semantics: saturating, NaN -> 0.
+// __float2int_rn / __float2int_rd of the reference: round, then convert with saturation, NaN -> 0.  That is what
+// v_cvt_i32_f32 does by itself (CDNA ISA: out-of-range inputs saturate, NaN converts to 0), so the three range tests a C
+// cast needs to stay defined -- nested branches in every projection -- are not needed.
 __device__ __forceinline__ int f2i_rn(float x) {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)__builtin_rintf(x);
+    int r;
+    asm("v_rndne_f32_e32 %0, %1\n\tv_cvt_i32_f32_e32 %0, %0" : "=v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ int f2i_rd(float x) {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)__builtin_floorf(x);
+    int r;
+    asm("v_floor_f32_e32 %0, %1\n\tv_cvt_i32_f32_e32 %0, %0" : "=v"(r) : "v"(x));
+    return r;
 }
 
 struct F3 { float x, y, z; };

@@ -24,7 +24,7 @@ struct IcpRow { float g[7]; float c[7]; };
 // trips; the arithmetic and its order are untouched).
 struct IcpModelPx { F3 np, vp; float ip; };   // ip = intensity of the model pixel (ICP.cu:100), the only use of its colour
 struct IcpCurrPx { F3 nc, s, cc; float gx, gy; };
-struct IcpProj { float d0, d1, d2, n0, n1, n2, az; int pu, pv; size_t pidx; };
+struct IcpProj { float d0, d1, d2, n0, n1, n2, az; int pu, pv; unsigned int pidx; };   // pidx < 2^28: launch_iter checks the image size
 
 __device__ __forceinline__ IcpModelPx icp_load_model(size_t indx, const float *__restrict__ VMap_prev,
                                                      const float *__restrict__ NMap_prev, const float *__restrict__ RGBD_prev) {
@@ -50,18 +50,20 @@ __device__ __forceinline__ IcpProj icp_project(const IcpModelPx &mp, const float
     int pv = f2i_rn((p.d1 / p.az) * intr[1] + intr[3]);
     p.pu = min(m - 1, max(0, pu));
     p.pv = min(n - 1, max(0, pv));
-    p.pidx = (size_t)p.pv * m + p.pu;
+    p.pidx = (unsigned int)p.pv * (unsigned int)m + (unsigned int)p.pu;
     return p;
 }
 __device__ __forceinline__ IcpCurrPx icp_gather(const IcpProj &p, const float *__restrict__ VMap, const float *__restrict__ NMap,
                                                 const float *__restrict__ RGB, const float *__restrict__ Gx, size_t gxp,
                                                 const float *__restrict__ Gy, size_t gyp) {
+    // 32-bit byte offsets from the (scalar) base pointers: one add per address instead of 64-bit multiply-adds
     IcpCurrPx c;
-    c.nc = ld3(NMap, p.pidx);
-    c.s = ld3(VMap, p.pidx);
-    c.cc = ld3(RGB, p.pidx);
-    c.gx = *(const float *)((const char *)Gx + (size_t)p.pv * gxp + 4 * (size_t)p.pu);
-    c.gy = *(const float *)((const char *)Gy + (size_t)p.pv * gyp + 4 * (size_t)p.pu);
+    const unsigned int o12 = 12u * p.pidx;
+    c.nc = *(const F3 *)((const char *)NMap + o12);
+    c.s = *(const F3 *)((const char *)VMap + o12);
+    c.cc = *(const F3 *)((const char *)RGB + o12);
+    c.gx = *(const float *)((const char *)Gx + ((unsigned int)p.pv * (unsigned int)gxp + 4u * (unsigned int)p.pu));
+    c.gy = *(const float *)((const char *)Gy + ((unsigned int)p.pv * (unsigned int)gyp + 4u * (unsigned int)p.pu));
     return c;
 }
 
@@ -80,7 +82,7 @@ __device__ __forceinline__ void icp_pin_gather(IcpCurrPx &c) {
 __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr, const IcpCurrPx &cu, const float *intr,
                                          float distThres, float angleThres, bool inside, IcpRow &o, int &proj) {
     const float d0 = pr.d0, d1 = pr.d1, d2 = pr.d2, n0 = pr.n0, n1 = pr.n1, n2 = pr.n2, az = pr.az;
-    const size_t pidx = pr.pidx;
+    const unsigned int pidx = pr.pidx;
     const float i_prev = mp.ip;
     const F3 nc = cu.nc;
     const F3 s = cu.s;
@@ -1282,6 +1284,12 @@ struct IcpMaps {
 };
 
 // One launch of k_icp_iter over block rows [br_lo, br_hi) of the level's 8x8-block grid.
+// the gathers address the maps with 32-bit byte offsets (icp_gather): 16 bytes per pixel and the pitched gradient images
+// must stay below 4 GB -- 268 M pixels, far beyond any depth camera
+static bool icp_offsets_fit(int n, int m, size_t gxp, size_t gyp) {
+    return (unsigned long long)n * (unsigned long long)m * 16ull <= 0xffffffffull && (unsigned long long)n * gxp <= 0xffffffffull &&
+           (unsigned long long)n * gyp <= 0xffffffffull;
+}
 static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, const float *t, const IcpMaps &mp,
                        float distThres, float angleThres, int n, int m, int fact, int br_lo, int br_hi, float *sums,
                        int32_t *corr, IcpState *state, const float *pose_state, int do_solve, int lvl, int iter, int max_iter,
@@ -1289,6 +1297,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
                        const IcpEndArgs *end = nullptr, const IcpXchg *xchg = nullptr) {
     int gr = div_up(n / fact, 8), gc = div_up(m / fact, 8);   // D1/ICP.cu:260-261
     if (gr <= 0 || gc <= 0) return RGBDSLAM_E_ARG;
+    if (!icp_offsets_fit(n, m, mp.gxp, mp.gyp)) return RGBDSLAM_E_ARG;
     if (br_lo < 0) br_lo = 0;
     if (br_hi > gr) br_hi = gr;
     if (br_hi <= br_lo) return RGBDSLAM_E_ARG;
@@ -1386,7 +1395,7 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
             ns += prm->max_iter[lvl] + 2;                      // iter = 0 .. max_iter+1 (RG.cpp:889)
         }
         for (int k = nl; k < 3; k++) { L.lv[k] = L.lv[0]; L.lv[k].w0 |= ICP_LV_UNUSED; }
-        if (gxp > 0xffffffffu || gyp > 0xffffffffu) return RGBDSLAM_E_ARG;
+        if (!icp_offsets_fit(n, m, gxp, gyp)) return RGBDSLAM_E_ARG;
         L.VMap = VMap; L.NMap = NMap; L.RGB = RGB; L.Gx = Gx; L.Gy = Gy; L.gxp = (unsigned int)gxp; L.gyp = (unsigned int)gyp;
         L.VMap_prev = VMap_prev; L.NMap_prev = NMap_prev; L.RGBD_prev = RGB_prev;
         L.block = ctx->icp_block; L.pb = pose_block; L.history = history; L.frame_index = frame_index;
