@@ -22,6 +22,7 @@ struct IcpRow { float g[7]; float c[7]; };
 // D1/ICP.cu:72-146 searchGauss + 164-205 row construction, split so that every memory access of a
 // stage is issued before anything waits on it (the kernel is a chain of dependent memory round
 // trips; the arithmetic and its order are untouched).
+struct IcpModelRaw { F3 np, vp; float cx, cy, cz; };   // a model sample as loaded
 struct IcpModelPx { F3 np, vp; float ip; };   // ip = intensity of the model pixel (ICP.cu:100), the only use of its colour
 struct IcpCurrPx { F3 nc, s, cc; float gx, gy; };
 struct IcpProj { float d0, d1, d2, n0, n1, n2, az; int pu, pv; unsigned int pidx; };   // pidx < 2^28: launch_iter checks the image size
@@ -34,6 +35,21 @@ __device__ __forceinline__ IcpModelPx icp_load_model(size_t indx, const float *_
     const float4 cp = *(const float4 *)(RGBD_prev + 4 * indx);
     // (float)((double)x / 3.0) == x / 3.0f for float x: double rounding is innocuous for division (53 >= 2*24 + 2)
     mp.ip = ((cp.x + cp.y) + cp.z) / 3.0f;                                       // ICP.cu:100
+    return mp;
+}
+__device__ __forceinline__ IcpModelRaw icp_load_model_raw(unsigned int indx, const float *__restrict__ VMap_prev,
+                                                          const float *__restrict__ NMap_prev, const float *__restrict__ RGBD_prev) {
+    IcpModelRaw mr;
+    mr.np = *(const F3 *)((const char *)NMap_prev + 12u * indx);
+    mr.vp = *(const F3 *)((const char *)VMap_prev + 12u * indx);
+    const F3 c = *(const F3 *)((const char *)RGBD_prev + 16u * indx);
+    mr.cx = c.x; mr.cy = c.y; mr.cz = c.z;
+    return mr;
+}
+__device__ __forceinline__ IcpModelPx icp_model_from_raw(const IcpModelRaw &mr) {
+    IcpModelPx mp;
+    mp.np = mr.np; mp.vp = mr.vp;
+    mp.ip = ((mr.cx + mr.cy) + mr.cz) / 3.0f;                                    // as icp_load_model
     return mp;
 }
 __device__ __forceinline__ IcpProj icp_project(const IcpModelPx &mp, const float *R, const float *t, const float *intr, int n, int m) {
@@ -73,6 +89,13 @@ __device__ __forceinline__ IcpCurrPx icp_gather(const IcpProj &p, const float *_
 __device__ __forceinline__ void icp_pin_gather(IcpCurrPx &c) {
     asm volatile("" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(c.cc.x), "+v"(c.cc.y),
                  "+v"(c.cc.z), "+v"(c.gx), "+v"(c.gy));
+}
+
+// the same pin on the path that has just requested the next level's samples (a distinct statement on purpose: merged with
+// the other one behind the join, the wait would have to cover the requests only one path has made -- all of them)
+__device__ __forceinline__ void icp_pin_gather_after_prefetch(IcpCurrPx &c) {
+    asm volatile("; gather before prefetch" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(c.cc.x),
+                 "+v"(c.cc.y), "+v"(c.cc.z), "+v"(c.gx), "+v"(c.gy));
 }
 
 // Returns false -> o untouched (the caller passes zeroed rows and needs no copy).  The four rejection tests of
@@ -227,6 +250,7 @@ __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
 #define ICP_XCHG_MAX_WORLD 8
 struct IcpXchg { unsigned int *peer[ICP_XCHG_MAX_WORLD]; int world, rank; unsigned int seq; };
 struct IcpIterArgs {
+    int nx_lvl, nx_rows, nx_cols;                    // persistent loop: the level after this one (-1: none), its block grid
     IcpXchg xchg;                                    // world == 0: no exchange
     const float *intr, *R, *t;                       // device scalars (user buffers or &IcpState fields)
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
@@ -277,7 +301,7 @@ struct IcpLoopCtl { unsigned int *pub; unsigned int base; int step, next_level, 
 __device__ __forceinline__ constexpr int icp_pub_slot(int k) { return k + k / 7; }
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
-                                               bool with_end, IcpEndArgs end, IcpLoopCtl lc);
+                                               bool with_end, IcpEndArgs end, IcpLoopCtl lc, long long *timing = nullptr);
 __device__ __forceinline__ void icp_begin_step(IcpState *st, const float *pose_state, const float *intr4);
 __device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArgs &e);
 
@@ -304,7 +328,9 @@ struct IcpShared {
 // loads could be served from a stale scalar or vector L1 line), and the tail publishes the next step.
 // persistent loop: the model pixels a wave samples in its first two rounds are the same for every iteration of a
 // level (only the pose changes), so they stay in registers from one step to the next
-struct IcpModelCache { IcpModelPx r0, r1; int lvl; bool in0, in1; };   // in*: the sample lies inside the image (locate)
+// in*: the sample lies inside the image (locate).  n0 / n1: the NEXT level's samples, requested during the first step of
+// this level (icp_iter_body) and still raw -- their intensity is formed when the level starts, so nothing waits on them
+struct IcpModelCache { IcpModelPx r0, r1; IcpModelRaw n0, n1; int lvl, nlvl; bool in0, in1, nin0, nin1; };
 // Line of the chain buffer that holds workgroup t's sums: the 32 workgroups c = 16j + 2v + h that wave v of the tail
 // folds (j = 0..15, h = 0..1) are stored back to back, in the order (j, h).
 __device__ __forceinline__ int icp_chain_line(int t) { return ((t >> 1) & 7) * 32 + ((t >> 4) << 1) + (t & 1); }
@@ -390,12 +416,19 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         inside = (i * a.fact < a.n && j * a.fact < a.m);
         idx = inside ? (size_t)(i * a.fact) * a.m + (size_t)(j * a.fact) : 0;
     };
+    bool want_next = false;                           // this step requests the next level's samples (after its own gather)
     if (LOOP) {
-        if (mc.lvl != a.lvl) {                        // first step of a level: both rounds' pixels are requested at once
-            mc.in0 = false; mc.in1 = false;
-            if (wv + ICP_CHAIN_WAVES < chain_len) { locate(wv + ICP_CHAIN_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); mc.in1 = inside; }
-            if (active) { locate(k); mc.r0 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); mc.in0 = inside; }
+        if (mc.lvl != a.lvl) {                        // first step of a level
+            if (mc.nlvl == a.lvl) {                   // its samples were requested a level ago
+                mc.r0 = icp_model_from_raw(mc.n0); mc.r1 = icp_model_from_raw(mc.n1);
+                mc.in0 = mc.nin0; mc.in1 = mc.nin1;
+            } else {                                  // first level of the frame: both rounds' pixels are requested at once
+                mc.in0 = false; mc.in1 = false;
+                if (wv + ICP_CHAIN_WAVES < chain_len) { locate(wv + ICP_CHAIN_WAVES); mc.r1 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); mc.in1 = inside; }
+                if (active) { locate(k); mc.r0 = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); mc.in0 = inside; }
+            }
             mc.lvl = a.lvl;
+            want_next = a.nx_lvl >= 0;
         }
         // later steps of the level: neither the block's position (two integer divisions) nor its model sample is recomputed
         // (idx is only needed for the correspondence map, which the persistent loop does not write)
@@ -416,11 +449,40 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     // a spill lane once per use -- two v_readlane per value per round.
     float Rc[9], tc3[3], in4[4];
 #pragma unroll
-    for (int z = 0; z < 9; z++) { Rc[z] = sst.Rcurr[z]; asm volatile("" : "+v"(Rc[z])); }
+    for (int z = 0; z < 9; z++) Rc[z] = sst.Rcurr[z];
 #pragma unroll
-    for (int z = 0; z < 3; z++) { tc3[z] = sst.tcurr[z]; asm volatile("" : "+v"(tc3[z])); }
+    for (int z = 0; z < 3; z++) tc3[z] = sst.tcurr[z];
 #pragma unroll
-    for (int z = 0; z < 4; z++) { in4[z] = sst.intr[z]; asm volatile("" : "+v"(in4[z])); }
+    for (int z = 0; z < 4; z++) in4[z] = sst.intr[z];
+    // (one statement: pinned one by one, every LDS read was waited for before the next was issued)
+    asm volatile("" : "+v"(Rc[0]), "+v"(Rc[1]), "+v"(Rc[2]), "+v"(Rc[3]), "+v"(Rc[4]), "+v"(Rc[5]), "+v"(Rc[6]), "+v"(Rc[7]), "+v"(Rc[8]),
+                 "+v"(tc3[0]), "+v"(tc3[1]), "+v"(tc3[2]), "+v"(in4[0]), "+v"(in4[1]), "+v"(in4[2]), "+v"(in4[3]));
+
+    // The model maps are 12.3 MB at full resolution: read when a level starts, they cost its first step ~3 us of memory
+    // time on top of the gather's.  Instead every wave requests its samples of the NEXT level during the first step of
+    // this one, AFTER its own gather (loads return in order) and without a branch around any single load (a wait behind a
+    // join has to assume the fewest requests): six unconditional loads, from pixel 0 where the wave has no block.
+    auto request_next = [&]() {
+        int nx_rows = a.nx_rows;
+        asm volatile("" : "+s"(nx_rows));             // opaque here: otherwise the index arithmetic (two integer divisions) is
+                                                      // hoisted out of the round loop and paid by every step
+        const int nfact = 1 << a.nx_lvl, nblk_n = nx_rows * a.nx_cols;
+        const int len_n = max(0, (nblk_n - tc + ICP_CHAINS - 1) / ICP_CHAINS);
+        unsigned int id[2];
+        bool in[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int kk = wv + h * ICP_CHAIN_WAVES;
+            const int blk = tc + ICP_CHAINS * kk;
+            const int i = (blk % nx_rows) * 8 + (lane >> 3), j = (blk / nx_rows) * 8 + (lane & 7);
+            in[h] = kk < len_n && i * nfact < a.n && j * nfact < a.m;
+            id[h] = in[h] ? (unsigned int)(i * nfact) * (unsigned int)a.m + (unsigned int)(j * nfact) : 0u;
+        }
+        mc.n0 = icp_load_model_raw(id[0], a.VMap_prev, a.NMap_prev, a.RGBD_prev);
+        mc.n1 = icp_load_model_raw(id[1], a.VMap_prev, a.NMap_prev, a.RGBD_prev);
+        mc.nin0 = in[0]; mc.nin1 = in[1];
+        mc.nlvl = a.nx_lvl;
+    };
 
     float acc = 0.0f;                                 // wave 0, lanes 0..26: running chain sum (ICP.cu:56-58)
     for (int r = 0; r < rounds; r++) {
@@ -438,7 +500,8 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
             IcpProj pr = icp_project(mp, Rc, tc3, in4, a.n, a.m);
             IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
-            icp_pin_gather(cu);
+            if (LOOP && r == 0 && want_next) { request_next(); icp_pin_gather_after_prefetch(cu); }
+            else icp_pin_gather(cu);
             int proj = -1;
             const bool ok = icp_rows(mp, pr, cu, in4, a.distThres, a.angleThres, inside, q, proj);
             if (!LOOP && a.corr && inside) a.corr[idx] = ok ? proj : -1;
@@ -465,7 +528,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             }
             float sum = fold27(v, lane, tr[wave]);
             if (lane < 27) part[wave][lane] = sum;
-        }
+        } else if (LOOP && r == 0 && want_next) request_next();   // a wave without a block at this level may have one at the next
         __syncthreads();
         if (wv == 0 && lane < 27) {                   // waves 0 and 5: one chain each
             int cnt = min(ICP_CHAIN_WAVES, chain_len - r * ICP_CHAIN_WAVES);
@@ -611,7 +674,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     if (a.do_solve) {
         IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
         icp_solve_step(&sst, a.state, fin, spose, a.lvl, a.iter, a.max_iter, a.thr_alpha, a.thr_tr, a.trace, solve_sh,
-                       a.final_launch != 0, e, lc);    // by value: a pointer to the local would put it in scratch memory
+                       a.final_launch != 0, e, lc, a.timing);    // by value: a pointer to the local would put it in scratch memory
     }
     if (a.timing && tid == 0) {
         a.timing[1] = ts0; a.timing[2] = ts1; a.timing[3] = ts2; a.timing[4] = ts3; a.timing[5] = ts4; a.timing[6] = wall_clock64();
@@ -679,7 +742,7 @@ void k_icp_loop(IcpLoopArgs L) {
     unsigned int *const pub = (unsigned int *)(L.block + ICP_OFF_PUB);
     int s = 0;
     IcpModelCache mc;
-    mc.lvl = -1;
+    mc.lvl = -1; mc.nlvl = -1;
     // what no later step refreshes: the pose pair of the frame and the intrinsics (a workgroup whose chain does not
     // exist at the coarsest level never runs step 0's begin)
     if (threadIdx.x < 24) spose_[threadIdx.x] = L.pb->pose_state[threadIdx.x];
@@ -707,6 +770,12 @@ void k_icp_loop(IcpLoopArgs L) {
             a.distThres = L.distThres; a.angleThres = L.angleThres;
             a.n = L.n; a.m = L.m;
             a.lvl = (int)(lw0 >> 28); a.max_iter = (int)((lw0 >> 16) & 0xfffu);
+            {
+                const unsigned int nw0 = in2 ? ICP_LV_UNUSED : (in1 ? L.lv[2].w0 : L.lv[1].w0);
+                const unsigned int nw1 = in1 ? L.lv[2].w1 : L.lv[1].w1;
+                a.nx_lvl = (nw0 & 0xffffu) == ICP_LV_UNUSED ? -1 : (int)(nw0 >> 28);
+                a.nx_rows = (int)(nw1 & 0xffffu); a.nx_cols = (int)(nw1 >> 16);
+            }
             a.fact = 1 << a.lvl; a.grid_rows = grid_rows; a.grid_cols = grid_cols;
             a.br_lo = 0; a.rows_local = grid_rows; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
             a.chains = (float *)(L.block + ICP_OFF_CHAINS);
@@ -909,21 +978,21 @@ __device__ __forceinline__ int llt_solve6_reg(const float *sums, float *x) {
 }
 
 // The same solve spread over the lanes of one wave: lane r (0..5) owns ROW r of the factor.  Column k of the factor is
-// independent across rows, so its five divisions and dot products run side by side; the forward substitution is done
-// column by column (each row still subtracts its products in ascending column order, as the serial loop does) and the
+// independent across rows, so its divisions and dot products run side by side.  The forward substitution rides along as
+// a SEVENTH row, b (lane 6): y[k] = (b[k] - sum_{p<k} L[k][p] y[p]) / L[k][k] is exactly the recurrence of a factor row
+// (the products commute, the subtractions come in the same ascending order), so it costs no instruction of its own.  The
 // backward substitution, whose rows must subtract in ascending order too, runs on the gathered factor.  Every element
 // sees exactly the operations of llt_solve6_reg in the same order: the bits are the same, the instruction count on the
 // critical path of the persistent loop drops from ~900 to ~400.  sums = 27 floats in LDS; x is valid in EVERY lane.
 __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, float *x) {
-    const int r = lane < 6 ? lane : 5;
+    const int r = lane < 6 ? lane : 6;
     float Arow[6], Lr[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int i = r < k ? r : k, j = r < k ? k : r;
-        Arow[k] = sums[i * 7 - (i * (i - 1)) / 2 + (j - i)];     // SYM_A(sums, r, k), per-lane LDS address
+        Arow[k] = sums[i * 7 - (i * (i - 1)) / 2 + (j - i)];     // SYM_A(sums, r, k) for r < 6, b[k] for r == 6
         Lr[k] = 0.0f;
     }
-    float v = sums[r * 7 - (r * (r - 1)) / 2 + (6 - r)];         // b[r]
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         float s = Arow[k], w = Arow[k], Lk[6];
@@ -931,7 +1000,7 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
         for (int p = 0; p < k; p++) {
             Lk[p] = lane_read(Lr[p], k);
             s = s - Lr[p] * Lr[p];                               // meaningful in lane k
-            w = w - Lr[p] * Lk[p];                               // meaningful in lanes r > k
+            w = w - Lr[p] * Lk[p];                               // meaningful in lanes r > k (lane 6: the forward substitution)
         }
         const float sk = lane_read(s, k);
         if (!(sk > 0.0f)) return 1;
@@ -940,10 +1009,7 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
     }
     float y[6];
 #pragma unroll
-    for (int p = 0; p < 6; p++) {                                // forward: y[p], then every later row takes its product off
-        y[p] = lane_read(v, p) / lane_read(Lr[p], p);
-        v = v - Lr[p] * y[p];
-    }
+    for (int p = 0; p < 6; p++) y[p] = lane_read(Lr[p], 6);
     float L[6][6];
 #pragma unroll
     for (int p = 0; p < 6; p++)
@@ -982,11 +1048,32 @@ __global__ void k_icp_begin(IcpState *st, const float *pose_state, CalibV c, int
     status[0] = 0; status[1] = 0;
 }
 
-// pose update of RG.cpp:874-889 for a solved increment x; st is a thread-private copy
-__device__ __forceinline__ void icp_pose_update(IcpState *st, const float *x, const float *pose_state, int lvl, int iter,
-                                                int max_iter, float thr_alpha, float thr_tr) {
-    st->iters = st->iters + 1;
-    st->lvl_iters = st->lvl_iters + (1 << (8 * lvl));
+// Pose update of RG.cpp:874-889 for a solved increment x, by ONE WAVE, in the lane layout of a published 128-byte line:
+// lane l < 32 (l % 8 != 7) owns word k = l - l/8 of IcpState -- k < 9 Rinv[k], 9..11 tinv, 12..20 Rcurr, 21..23 tcurr.  x is
+// valid in every lane; the quaternion -> matrix part (f64) and the convergence test run redundantly in all lanes, the
+// 3x3 products element-wise, each element with the operations and the order of d_mat3_mul / d_mat3_vec; the new Rinv /
+// tinv reach the lanes that form Rcurr / tcurr through lane reads.  The result is the lane's word of the NEW state: it is
+// stored to the line (and to LDS) as it is -- no copy of the state, no LDS round trip between update and publication.
+// As one thread on a private copy this was ~250 dependent-issue instructions plus 56 LDS accesses per iteration.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ constexpr int icp_slot_of_word(int k) { return k + k / 7; }
+// old_word: word k of the current state (what the lane keeps where nothing changes).  Returns the new word k.
+__device__ __forceinline__ float icp_pose_update_wave(const IcpState *st, const float *x, const float *pose_state, int lvl, int iter,
+                                                      int max_iter, float thr_alpha, float thr_tr, int k, float old_word, int &cvg_out) {
+    // everything the update reads from LDS, requested before the arithmetic
+    const bool role_b = k >= 12;                                   // this lane forms a word of Rcurr / tcurr
+    const int kk = role_b ? k - 12 : k;
+    const bool is_t = kk >= 9;                                     // ... of tinv / tcurr
+    const int e = is_t ? (kk - 9) % 3 : kk % 9, i = e % 3, c = is_t ? 0 : e / 3;
+    const float *col = is_t ? st->tinv : st->Rinv + 3 * c;         // old tinv | column c of the old Rinv
+    const float b0 = col[0], b1 = col[1], b2 = col[2];
+    const float *pc = is_t ? pose_state + 21 : pose_state + 12 + 3 * c;   // tPrev | column c of RPrev
+    const float p0 = pc[0], p1 = pc[1], p2 = pc[2];
+
     double q[4];
     double nrm = (double)((x[3] * x[3] + x[4] * x[4]) + x[5] * x[5]);   // RG.cpp:875
     q[1] = x[3]; q[2] = x[4]; q[3] = x[5]; q[0] = __builtin_sqrt(1 - nrm);
@@ -1004,22 +1091,40 @@ __device__ __forceinline__ void icp_pose_update(IcpState *st, const float *x, co
     M3(Rinc, 2, 0) = (float)(2.0 * (q13 - q02));
     M3(Rinc, 1, 2) = (float)(2.0 * (q23 - q01));
     M3(Rinc, 2, 1) = (float)(2.0 * (q23 + q01));
-    float tinc[3] = {x[0], x[1], x[2]}, tmp[3];
-    d_mat3_vec(Rinc, st->tinv, tmp);                           // RG.cpp:886
-    st->tinv[0] = tmp[0] + tinc[0]; st->tinv[1] = tmp[1] + tinc[1]; st->tinv[2] = tmp[2] + tinc[2];
-    d_mat3_mul(Rinc, st->Rinv, st->Rinv);                      // RG.cpp:887
-    int cvg = (iter > max_iter) || (d_frob_minus_I(Rinc) < thr_alpha && d_norm3(tinc) < thr_tr);  // RG.cpp:889
-    st->cvg = cvg;
+    const float tinc[3] = {x[0], x[1], x[2]};
+    const int cvg = (iter > max_iter) || (d_frob_minus_I(Rinc) < thr_alpha && d_norm3(tinc) < thr_tr);  // RG.cpp:889
+    cvg_out = cvg;
+    // row i of Rinc
+    const float a0 = i == 0 ? Rinc[0] : (i == 1 ? Rinc[1] : Rinc[2]);
+    const float a1 = i == 0 ? Rinc[3] : (i == 1 ? Rinc[4] : Rinc[5]);
+    const float a2 = i == 0 ? Rinc[6] : (i == 1 ? Rinc[7] : Rinc[8]);
+    float nv = (a0 * b0 + a1 * b1) + a2 * b2;                      // RG.cpp:887 element (i, c) | RG.cpp:886 row i
+    if (is_t) nv = nv + (i == 0 ? tinc[0] : (i == 1 ? tinc[1] : tinc[2]));
+    // (meaningful in the lanes of words 0..11; the others computed the same element a second time)
     // Refresh the uploaded pair (RG.cpp:851-852) for whichever iteration runs next: the next one of
     // this level (iff !cvg) or iteration 0 of the next level (always).  After the final executed
     // iteration of level 0 the pair is left untouched: the track-loss test reads the LAST
     // uploaded pair, not the final estimate (RG.cpp:910).
-    if (!cvg || lvl > 0) d_set_rt_curr(st, pose_state);
+    float cv = old_word;
+    if (!cvg || lvl > 0) {
+        float nR[9], nt[3];
+#pragma unroll
+        for (int z = 0; z < 9; z++) nR[z] = lane_read(nv, icp_slot_of_word(z));          // the new Rinv
+#pragma unroll
+        for (int z = 0; z < 3; z++) nt[z] = lane_read(nv, icp_slot_of_word(9 + z));      // the new tinv
+        const float r0 = i == 0 ? nR[0] : (i == 1 ? nR[1] : nR[2]);                      // its row i
+        const float r1 = i == 0 ? nR[3] : (i == 1 ? nR[4] : nR[5]);
+        const float r2 = i == 0 ? nR[6] : (i == 1 ? nR[7] : nR[8]);
+        cv = (r0 * p0 + r1 * p1) + r2 * p2;                                              // RG.cpp:851 | 852
+        if (is_t) cv = cv + (i == 0 ? nt[0] : (i == 1 ? nt[1] : nt[2]));
+    }
+    return role_b ? cv : nv;
 }
 
+// st: the state in LDS (updated in place); out: where the multi-launch forms keep it between launches
 __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, const float *sums, const float *pose_state, int lvl,
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
-                                               bool with_end, IcpEndArgs end, IcpLoopCtl lc) {
+                                               bool with_end, IcpEndArgs end, IcpLoopCtl lc, long long *timing) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float x[6];
     int llt_fail = 0;
@@ -1030,53 +1135,58 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         llt_fail = wave_llt_solve6(sums, lane, x);             // RG.cpp:873 (wave-uniform result)
     }
     __syncthreads();
-    if (lc.pub ? wave != 0 : threadIdx.x != 0) return;
-    IcpState loc;
-    int nxt = 0;
-    if (threadIdx.x == 0) {
-        icp_state_copy(&loc, st);
-        float det = sh[0];
-        if ((double)__builtin_fabsf(det) < 1e-15 || det != det || llt_fail) {   // RG.cpp:864-871
-            loc.fail = 1;
-        } else {
-            if (trace) {
-                float *tr = trace + 33 * loc.iters;
-                for (int k = 0; k < 27; k++) tr[k] = sums[k];
-                for (int k = 0; k < 6; k++) tr[27 + k] = x[k];
-            }
-            icp_pose_update(&loc, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr);
+    if (wave != 0) return;
+    if (timing && lane == 0) timing[7] = wall_clock64();      // debug build: determinant and solve are done
+    const int k = lane - (lane >> 3);                          // word of the state this lane owns (inverse of icp_pub_slot)
+    const bool owner = lane < 32 && (lane & 7) != 7 && k < 24;
+    const int kr = owner ? k : 0;
+    float word = ((const float *)st)[kr];
+    int iters = st->iters, lvl_iters = st->lvl_iters, cvg = st->cvg, fail = 0;
+    const float det = sh[0];
+    if ((double)__builtin_fabsf(det) < 1e-15 || det != det || llt_fail) {   // RG.cpp:864-871
+        fail = 1;
+    } else {
+        if (trace && lane == 0) {
+            float *tr = trace + 33 * iters;
+            for (int z = 0; z < 27; z++) tr[z] = sums[z];
+            for (int z = 0; z < 6; z++) tr[27 + z] = x[z];
         }
-        if (lc.pub) {
-            // persistent loop: a failed solve ends the loop, a converged level continues at the next level
-            nxt = loc.fail ? lc.nsteps : (loc.cvg ? lc.next_level : lc.step + 1);
-            icp_state_copy(st, &loc);                          // LDS: the publishing lanes pick their words up from here
-        }
+        word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, cvg);
+        iters = iters + 1;
+        lvl_iters = lvl_iters + (1 << (8 * lvl));
     }
+    if (owner) ((float *)st)[k] = word;
+    if (lane == 0) { st->iters = iters; st->lvl_iters = lvl_iters; st->cvg = cvg; st->fail = fail; }
     if (lc.pub) {
+        // persistent loop: a failed solve ends the loop, a converged level continues at the next level
+        const int nxt = fail ? lc.nsteps : (cvg ? lc.next_level : lc.step + 1);
         // ONE wave-wide store publishes the line (a single 128-byte write instead of 25 word stores to a line that 512
         // workgroups are polling: those were acknowledged slowly and the ordering fence waited for them)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        nxt = __builtin_amdgcn_readfirstlane(nxt);
-        {
-            const int k = lane - (lane >> 3);                  // inverse of icp_pub_slot
-            unsigned int word = 0u;
-            if (lane < 32 && k < 24) word = ((const unsigned int *)st)[k];
-            if (lane < 32 && k == 24)
-                word = (unsigned int)(st->lvl_iters & 0xffffff) | ((unsigned int)(st->cvg != 0) << 24) | ((unsigned int)(st->fail != 0) << 25);
-            if ((lane & 7) == 7) word = lc.base + (unsigned int)nxt;
-            if (lc.check) {                                    // slot 30: integrity word of the 25 data words
-                const unsigned int chk = icp_line_xor_lo(word, lane);
-                if (lane == 30) word = chk;
-            }
-            if (lane < 32) __hip_atomic_store(lc.pub + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int w = owner ? __float_as_uint(word) : 0u;
+        if (lane < 32 && k == 24) w = (unsigned int)(lvl_iters & 0xffffff) | ((unsigned int)(cvg != 0) << 24) | ((unsigned int)(fail != 0) << 25);
+        if ((lane & 7) == 7) w = lc.base + (unsigned int)nxt;
+        if (lc.check) {                                        // slot 30: integrity word of the 25 data words
+            const unsigned int chk = icp_line_xor_lo(w, lane);
+            if (lane == 30) w = chk;
         }
-        if (threadIdx.x == 0 && nxt >= lc.nsteps) icp_end_step(&loc, end);
+        if (lane < 32) __hip_atomic_store(lc.pub + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nxt >= lc.nsteps) {
+            wave_lds_sync();
+            if (lane == 0) {
+                IcpState loc;
+                icp_state_copy(&loc, st);
+                icp_end_step(&loc, end);
+            }
+        }
         return;
     }
-    icp_state_copy(out, &loc);
-    if (with_end) icp_end_step(&loc, end);
+    wave_lds_sync();
+    if (lane == 0) {
+        IcpState loc;
+        icp_state_copy(&loc, st);
+        icp_state_copy(out, &loc);
+        if (with_end) icp_end_step(&loc, end);
+    }
 }
 
 // stand-alone solve for the row-sharded path (launch with 128 threads): sums = sum over `parts`
@@ -1303,6 +1413,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     if (br_hi <= br_lo) return RGBDSLAM_E_ARG;
     if (!ctx->buf_dev) return RGBDSLAM_E_STATE;
     IcpIterArgs a;
+    a.nx_lvl = -1; a.nx_rows = 1; a.nx_cols = 1;
     if (xchg) a.xchg = *xchg; else a.xchg.world = 0;
     a.fault = ctx->icp_epoch_dev ? (int *)(ctx->icp_epoch_dev + 32) : nullptr;
     a.line_check = ctx->icp_line_check; a.rejections = ctx->icp_epoch_dev ? ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD : nullptr;

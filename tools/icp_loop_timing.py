@@ -40,7 +40,8 @@ for s in sorted(acc):
     gap = ""
     if prev_end is not None and len(prev_end) == len(a):
         gap = "hand-over %5.0f ns (previous publication -> this tail workgroup starts)" % ((a[:, 1] - prev_end).mean() * 10.0)
-    print("step %2d (%2d frames): rounds %6.0f | store %5.0f | - %5.0f | lines+tree %5.0f | solve+pub %5.0f | sum %6.0f ns   %s"
-          % (s, len(a), *ph, ph.sum(), gap))
+    solve = ((a[:, 7] - a[:, 5]).mean() * 10.0) if (a[:, 7] > 0).all() else float("nan")   # barrier + det || solve + barrier
+    print("step %2d (%2d frames): rounds %6.0f | store %5.0f | - %5.0f | lines+tree %5.0f | solve+pub %5.0f (det/solve %5.0f) | sum %6.0f ns   %s"
+          % (s, len(a), *ph, solve, ph.sum(), gap))
     prev_end = a[:, 6]
 rg.close()
