@@ -1126,22 +1126,27 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
                                                int iter, int max_iter, float thr_alpha, float thr_tr, float *trace, float *sh,
                                                bool with_end, IcpEndArgs end, IcpLoopCtl lc, long long *timing) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float x[6];
-    int llt_fail = 0;
+    const int k = lane - (lane >> 3);                          // word of the state this lane owns (inverse of icp_pub_slot)
+    const bool owner = lane < 32 && (lane & 7) != 7 && k < 24;
+    const int kr = owner ? k : 0;
+    float x[6], word = 0.0f, new_word = 0.0f;
+    int llt_fail = 0, iters = 0, lvl_iters = 0, cvg = 0, new_cvg = 0;
+    // The determinant (wave 1) is only consulted for the singularity test, and it takes longer than the solve: wave 0 does
+    // not wait for it but goes on to the pose update, in registers; the two meet at the barrier and the test then picks
+    // the new or the old words.
     if (wave == 1) {
         float det = wave_det6(sums, lane);                     // RG.cpp:862, concurrently with the solve
         if (lane == 0) sh[0] = det;
     } else if (wave == 0) {
+        word = ((const float *)st)[kr];
+        iters = st->iters; lvl_iters = st->lvl_iters; cvg = st->cvg;
         llt_fail = wave_llt_solve6(sums, lane, x);             // RG.cpp:873 (wave-uniform result)
+        if (!llt_fail) new_word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, new_cvg);
     }
     __syncthreads();
     if (wave != 0) return;
-    if (timing && lane == 0) timing[7] = wall_clock64();      // debug build: determinant and solve are done
-    const int k = lane - (lane >> 3);                          // word of the state this lane owns (inverse of icp_pub_slot)
-    const bool owner = lane < 32 && (lane & 7) != 7 && k < 24;
-    const int kr = owner ? k : 0;
-    float word = ((const float *)st)[kr];
-    int iters = st->iters, lvl_iters = st->lvl_iters, cvg = st->cvg, fail = 0;
+    if (timing && lane == 0) timing[7] = wall_clock64();      // debug build: determinant, solve and update are done
+    int fail = 0;
     const float det = sh[0];
     if ((double)__builtin_fabsf(det) < 1e-15 || det != det || llt_fail) {   // RG.cpp:864-871
         fail = 1;
@@ -1151,7 +1156,7 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
             for (int z = 0; z < 27; z++) tr[z] = sums[z];
             for (int z = 0; z < 6; z++) tr[27 + z] = x[z];
         }
-        word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, cvg);
+        word = new_word; cvg = new_cvg;
         iters = iters + 1;
         lvl_iters = lvl_iters + (1 << (8 * lvl));
     }
