@@ -10,7 +10,7 @@
 #include "common.hpp"
 #include <string.h>
 
-#define ICP_CHAIN_WAVES 5  // waves (= 8x8 blocks in flight) per chain: 640x480 has 9.4 blocks per chain -> two balanced rounds
+#define ICP_CHAIN_WAVES 6  // waves per chain: 12 waves per workgroup = 3 on every SIMD (10 left two SIMDs with 3 and two with 2, and the loaded pair set the pace); 640x480 has 9.4 blocks per chain -> rounds of 6 + 3.4
 #define ICP_WG_CHAINS 2    // a workgroup owns chains t and t+256 and adds their sums itself (first level of reduce<512>):
                            // half as many sums to publish, to count and -- the expensive part -- to read back in the tail
 #define ICP_MAX_WAVES (ICP_CHAIN_WAVES * ICP_WG_CHAINS)
