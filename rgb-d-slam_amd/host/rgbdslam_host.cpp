@@ -3,6 +3,9 @@
 #include "rgbdslam_host.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <future>
+#include <stdio.h>
 
 #include <math.h>
 #include <stdlib.h>
@@ -790,8 +793,23 @@ void RG::SetPlanes(const float *equations, const float *centers, int nbPlan) {
     CreatePrimitives(pose);
 }
 
+// RGBDSLAM_FINISH_TIMING=1: stage times of a detection / of RG::Finish's periodic cycle on stderr (wall clock, ms)
+struct StageTimer {
+    bool on; const char *what; std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(const char *w) : what(w) {
+        static const bool enabled = getenv("RGBDSLAM_FINISH_TIMING") != nullptr;
+        on = enabled;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~StageTimer() {
+        if (on) fprintf(stderr, "[finish timing] %-28s %8.3f ms\n", what,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // RG.cpp:277-694.  Image stages on the GPU, median fit on the host (as in the reference, RG.cpp:393-679).
 void RG::DetectPrimitives(float *pose) {
+    StageTimer st_all("DetectPrimitives");
     const int n = _predicted_frame->_n, m = _predicted_frame->_m;
     const size_t P = (size_t)n * m;
     hipStream_t s = ctx_stream(_ctx);
@@ -801,6 +819,7 @@ void RG::DetectPrimitives(float *pose) {
     hip_check(hipMemsetAsync(_predicted_frame->_Label_dev, 0, P, s), "memset label");                      // RG.cpp:313
     check(rgbdslam_detect_regions(_ctx, _predicted_frame->getNMap(), _predicted_frame->getVMap(), nullptr, 120.0, 30.0, 0.03f, 20,
                                   _blob_dev.p, _blob_sizes_dev.p, _detect_labels.p, _detect_bytes.p, n, m), "detect_regions");
+    StageTimer *st_dl = new StageTimer("  regions + 4 downloads");
     std::vector<int32_t> blob(P), sizes(P);
     std::vector<float> VMap_cpu(3 * P), NMap_cpu(3 * P);                              // RG.cpp:394-396
     std::vector<uint8_t> Label_cpu(P, 0);
@@ -809,6 +828,8 @@ void RG::DetectPrimitives(float *pose) {
     hip_check(hipMemcpyAsync(VMap_cpu.data(), _predicted_frame->getVMap(), 12 * P, hipMemcpyDeviceToHost, s), "VMap download");
     hip_check(hipMemcpyAsync(NMap_cpu.data(), _predicted_frame->getNMap(), 12 * P, hipMemcpyDeviceToHost, s), "NMap download");
     hip_check(hipStreamSynchronize(s), "sync");
+    delete st_dl;
+    StageTimer st_fit("  host median fit + labels");
 
     _nbPlan = 0;                                                                      // RG.cpp:401
     _Equations.clear(); _Centers.clear();
@@ -819,46 +840,49 @@ void RG::DetectPrimitives(float *pose) {
     _Detect = !roots.empty();                                                         // RG.cpp:385-390
     if (!_Detect) return;
     const int max_labels = 255;
-    for (size_t root : roots) {
-        if (_nbPlan >= max_labels) break;
+    // The fit of one blob is independent of the others' (the reference runs them one after the other on one core: ~8 ms for
+    // three 100 000-pixel planes, the bulk of RG::Finish's periodic cycle): one task per blob, its three normal medians side
+    // by side; what depends on the order of the blobs -- plane numbers, the 255 cap -- is applied afterwards, in order.
+    // Inside a blob every sum runs in the reference's pixel order, so the results are the same bits.
+    struct BlobFit { bool accepted = false; float eq[10]; float center[3]; std::vector<uint32_t> px; };
+    std::vector<BlobFit> fits(roots.size());
+    auto fit_blob = [&](size_t root, BlobFit &out) {
         const int curr_size = sizes[root];
-        std::vector<size_t> px;
+        std::vector<uint32_t> &px = out.px;
         px.reserve((size_t)curr_size);
         for (size_t p = root; p < P && (int)px.size() < curr_size; p++)
-            if (blob[p] == (int32_t)root) px.push_back(p);
+            if (blob[p] == (int32_t)root) px.push_back((uint32_t)p);
         std::vector<float> Nx((size_t)curr_size, 0.0f), Ny((size_t)curr_size, 0.0f), Nz((size_t)curr_size, 0.0f);
         int count = 0;
         for (int j = 0; j < curr_size; j++) {                                         // RG.cpp:479-497
-            const float *N = &NMap_cpu[3 * px[j]];
+            const float *N = &NMap_cpu[3 * (size_t)px[j]];
             if (N[0] == 0.0f && N[1] == 0.0f && N[2] == 0.0f) continue;               // such entries stay 0 in the lists
             count++;
             Nx[j] = (N[0] * pose[0] + N[1] * pose[4]) + N[2] * pose[8];
             Ny[j] = (N[0] * pose[1] + N[1] * pose[5]) + N[2] * pose[9];
             Nz[j] = (N[0] * pose[2] + N[1] * pose[6]) + N[2] * pose[10];
         }
-        if (count < min_normals_plan) continue;                                       // RG.cpp:500-516
+        if (count < min_normals_plan) return;                                         // RG.cpp:500-516
         // RG.cpp:521-533 sorts the three lists and takes the middle elements: the same elements by selection
-        std::nth_element(Nx.begin(), Nx.begin() + Nx.size() / 2, Nx.end());
-        std::nth_element(Ny.begin(), Ny.begin() + Ny.size() / 2, Ny.end());
-        std::nth_element(Nz.begin(), Nz.begin() + Nz.size() / 2, Nz.end());
-        float nmle[3] = {Nx[Nx.size() / 2], Ny[Ny.size() / 2], Nz[Nz.size() / 2]};
+        auto mid = [](std::vector<float> &v) { std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return v[v.size() / 2]; };
+        std::future<float> fy = std::async(std::launch::async, mid, std::ref(Ny)), fz = std::async(std::launch::async, mid, std::ref(Nz));
+        float nmle[3];
+        nmle[0] = mid(Nx); nmle[1] = fy.get(); nmle[2] = fz.get();
         float norm_nmle = sqrtf((nmle[0] * nmle[0] + nmle[1] * nmle[1]) + nmle[2] * nmle[2]);
         nmle[0] = nmle[0] / norm_nmle; nmle[1] = nmle[1] / norm_nmle; nmle[2] = nmle[2] / norm_nmle;
         std::vector<float> Dists((size_t)curr_size);
         float center_curr[3] = {0.0f, 0.0f, 0.0f};
         for (int j = 0; j < curr_size; j++) {                                         // RG.cpp:557-578
-            const float *V = &VMap_cpu[3 * px[j]];
+            const float *V = &VMap_cpu[3 * (size_t)px[j]];
             float pt[3];
             pt[0] = ((V[0] * pose[0] + V[1] * pose[4]) + V[2] * pose[8]) + pose[12];
             pt[1] = ((V[0] * pose[1] + V[1] * pose[5]) + V[2] * pose[9]) + pose[13];
             pt[2] = ((V[0] * pose[2] + V[1] * pose[6]) + V[2] * pose[10]) + pose[14];
             center_curr[0] = center_curr[0] + pt[0]; center_curr[1] = center_curr[1] + pt[1]; center_curr[2] = center_curr[2] + pt[2];
             Dists[j] = (pt[0] * nmle[0] + pt[1] * nmle[1]) + pt[2] * nmle[2];
-            Label_cpu[px[j]] = (uint8_t)(_nbPlan + 1);
         }
-        for (int k = 0; k < 3; k++) _Centers.push_back(center_curr[k] / (float)curr_size);   // RG.cpp:581-583
-        std::nth_element(Dists.begin(), Dists.begin() + Dists.size() / 2, Dists.end());   // RG.cpp:592-598 (sort + middle element)
-        const float dist = Dists[Dists.size() / 2];
+        for (int k = 0; k < 3; k++) out.center[k] = center_curr[k] / (float)curr_size;   // RG.cpp:581-583
+        const float dist = mid(Dists);                                                // RG.cpp:592-598 (sort + middle element)
         float e1[3], e2[3];                                                           // RG.cpp:607-637
         if (nmle[0] > nmle[1] && nmle[0] > nmle[2]) { e1[0] = -nmle[1]; e1[1] = nmle[0]; e1[2] = 0.0f; }
         else if (nmle[1] > nmle[0] && nmle[1] > nmle[2]) { e1[0] = 0.0f; e1[1] = -nmle[2]; e1[2] = nmle[1]; }
@@ -869,7 +893,24 @@ void RG::DetectPrimitives(float *pose) {
         e2[1] = nmle[2] * e1[0] - nmle[0] * e1[2];
         e2[2] = nmle[0] * e1[1] - nmle[1] * e1[0];
         const float eq[10] = {nmle[0], nmle[1], nmle[2], e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], dist};
-        _Equations.insert(_Equations.end(), eq, eq + 10);
+        memcpy(out.eq, eq, sizeof(eq));
+        out.accepted = true;
+    };
+    {
+        std::vector<std::future<void>> tasks;
+        for (size_t r = 1; r < roots.size(); r++)
+            tasks.push_back(std::async(std::launch::async, fit_blob, roots[r], std::ref(fits[r])));
+        fit_blob(roots[0], fits[0]);
+        for (auto &t : tasks) t.get();
+    }
+    for (size_t r = 0; r < roots.size(); r++) {
+        if (_nbPlan >= max_labels) break;
+        const BlobFit &f = fits[r];
+        if (!f.accepted) continue;
+        const uint8_t label = (uint8_t)(_nbPlan + 1);
+        for (uint32_t p : f.px) Label_cpu[p] = label;
+        for (int k = 0; k < 3; k++) _Centers.push_back(f.center[k]);
+        _Equations.insert(_Equations.end(), f.eq, f.eq + 10);
         _nbPlan++;
     }
     hip_check(hipMemcpy(_predicted_frame->_Label_dev, Label_cpu.data(), P, hipMemcpyHostToDevice), "label upload");   // RG.cpp:590
@@ -880,8 +921,9 @@ int RG::DetectPlanes() {                                                        
     SyncAll();
     float pose[16];
     pack_pose(_poseR, _poset, pose);
-    _graph->Clear();
+    { StageTimer st("Graph::Clear"); _graph->Clear(); }
     DetectPrimitives(pose);
+    StageTimer st("CreatePrimitives");
     CreatePrimitives(pose, true);
     return _nbPlan;
 }
@@ -894,7 +936,9 @@ void RG::Finish() {
     const bool first_due = _first_in && _count > finish_first_after;                  // RG.cpp:154
     const bool period_due = !first_due && finish_period > 0 && (_count % finish_period) == 0;   // RG.cpp:187
     if (!first_due && !period_due) return;
+    StageTimer st_cycle("RG::Finish (whole)");
     if (fused) {
+        StageTimer st("Sync (drain the queue)");
         if (Sync() == 0) return;                                                      // lost frame: display() jumps over Finish
     }
     if (first_due) {
@@ -910,7 +954,7 @@ void RG::Finish() {
     }
     _poseRPrev = _poseR;                                                              // RG.cpp:189-190
     _posetPrev = _poset;
-    if (ok2Save) { SaveModel(save_dir.c_str(), _indx); finish_dumps++; }              // RG.cpp:209-232 (+ SaveThread, RG.cpp:16-59)
+    if (ok2Save) { StageTimer st("SaveModel"); SaveModel(save_dir.c_str(), _indx); finish_dumps++; }   // RG.cpp:209-232 (+ SaveThread, RG.cpp:16-59)
     _indx++;                                                                          // RG.cpp:234
     DetectPlanes();                                                                   // RG.cpp:253-268: tables freed, planes re-detected
     finish_detections++;
