@@ -60,31 +60,79 @@ __device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) { return is_zero
 
 // grid over n x m pixels: quad (i, j) for i < n-1, j < m-1; when the tracker lost the frame the same
 // grid re-seeds the model instead (GP-demo.cpp:189-193) -- no separate launch that usually does nothing.
-__global__ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
-                               unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
-                               ReseedArgs rs, int n, int m) {
-    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    // The tracked flag was written by the launch before this one: reading it is a memory round trip.  The quad's
+// The kernel is VALU-issue bound (822 instructions per wave at 1920 x 1080 = 43 us of issue time, 43.5 us measured; the
+// z-buffer atomics are ~1 per pixel and do not show), so a vertex is warped and projected ONCE per workgroup, not once per
+// quad that uses it: the 65 x 5 vertices of a 64 x 4 quad tile go through LDS (two f32 divisions, one f64 reciprocal and
+// the 3x4 warp per vertex: ~110 instructions, four times per quad before).
+#define PD_ROWS (TILE_H + 1)
+#define PD_COLS (TILE_W + 1)
+struct PdVert { F3 v; RasVert p; };
+__device__ __forceinline__ PdVert pd_vertex(const float *P, const CalibV &c, F3 v, bool exists) {
+    PdVert o;
+    o.v = warp_vertex(P, v);
+    o.p = ras_project(o.v, c);
+    if (!exists) { o.v.x = o.v.y = o.v.z = 0.0f; o.p.X = 0; o.p.Y = 0; o.p.inv_d = 0.0; o.p.ok = false; }
+    return o;
+}
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
+                    unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
+                    ReseedArgs rs, int n, int m) {
+    // structure of arrays, one word per lane and field: no bank conflicts
+    __shared__ float s_v[3][PD_ROWS][PD_COLS];
+    __shared__ int s_xy[2][PD_ROWS][PD_COLS];
+    __shared__ double s_inv[PD_ROWS][PD_COLS];
+    __shared__ uint8_t s_ok[PD_ROWS][PD_COLS];
+    const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+    const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    // The tracked flag was written by the launch before this one: reading it is a memory round trip.  The tile's
     // vertices are requested in the same round trip; the flag is only looked at before the first side effect.
     const bool tracked = pb_tracked(pb);
-    const bool quad = !(i > n - 2 || j > m - 2);
     const float *P = pb->P_rel;
-    uint32_t q = quad ? (uint32_t)(i * (m - 1) + j) : 0u, id[4];
-    quad_vertex_ids(q, nullptr, m, id);
-    F3 v0 = ld3(VMap, id[0]), v1 = ld3(VMap, id[1]), v2 = ld3(VMap, id[2]), v3 = ld3(VMap, id[3]);
-    pin_loaded(v0); pin_loaded(v1); pin_loaded(v2); pin_loaded(v3);    // four loads in flight, then the warps
+    // vertex (threadIdx.y, threadIdx.x) of the tile, and for the first 69 threads one of the extra row / column
+    const bool ex1 = i < n && j < m;
+    const bool second = tid < PD_COLS + TILE_H;
+    const int r2 = tid < PD_COLS ? TILE_H : tid - PD_COLS, c2 = tid < PD_COLS ? tid : TILE_W;
+    const bool ex2 = second && i0 + r2 < n && j0 + c2 < m;
+    F3 v1 = ld3(VMap, ex1 ? (size_t)i * m + j : 0);
+    F3 v2 = ld3(VMap, ex2 ? (size_t)(i0 + r2) * m + (j0 + c2) : 0);
+    pin_loaded(v1); pin_loaded(v2);
     if (!tracked) {
         if (rs.fV && i < n && j < m) reseed_pixel(rs, c, i, j, n, m);
         return;
     }
-    if (!quad) return;
-    v0 = warp_vertex(P, v0); v1 = warp_vertex(P, v1); v2 = warp_vertex(P, v2); v3 = warp_vertex(P, v3);
-    if (quad_trimmed(v0, v1, v2, v3, thresh)) return;
-    // triangles (0,1,2) and (0,2,3): the four vertices are projected once
-    const RasVert p0 = ras_project(v0, c), p1 = ras_project(v1, c), p2 = ras_project(v2, c), p3 = ras_project(v3, c);
+    {
+        const PdVert a = pd_vertex(P, c, v1, ex1);
+        s_v[0][threadIdx.y][threadIdx.x] = a.v.x; s_v[1][threadIdx.y][threadIdx.x] = a.v.y; s_v[2][threadIdx.y][threadIdx.x] = a.v.z;
+        s_xy[0][threadIdx.y][threadIdx.x] = a.p.X; s_xy[1][threadIdx.y][threadIdx.x] = a.p.Y;
+        s_inv[threadIdx.y][threadIdx.x] = a.p.inv_d; s_ok[threadIdx.y][threadIdx.x] = a.p.ok ? 1 : 0;
+    }
+    if (second) {
+        const PdVert a = pd_vertex(P, c, v2, ex2);
+        s_v[0][r2][c2] = a.v.x; s_v[1][r2][c2] = a.v.y; s_v[2][r2][c2] = a.v.z;
+        s_xy[0][r2][c2] = a.p.X; s_xy[1][r2][c2] = a.p.Y;
+        s_inv[r2][c2] = a.p.inv_d; s_ok[r2][c2] = a.p.ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (i > n - 2 || j > m - 2) return;               // no quad here
+    const uint32_t q = (uint32_t)(i * (m - 1) + j);
+    // corners in the order of quad_vertex_ids: (i, j) (i, j+1) (i+1, j+1) (i+1, j)
+    const int rr[4] = {(int)threadIdx.y, (int)threadIdx.y, (int)threadIdx.y + 1, (int)threadIdx.y + 1};
+    const int cc[4] = {(int)threadIdx.x, (int)threadIdx.x + 1, (int)threadIdx.x + 1, (int)threadIdx.x};
+    F3 w[4];
+    RasVert p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        w[k].x = s_v[0][rr[k]][cc[k]]; w[k].y = s_v[1][rr[k]][cc[k]]; w[k].z = s_v[2][rr[k]][cc[k]];
+        p[k].X = s_xy[0][rr[k]][cc[k]]; p[k].Y = s_xy[1][rr[k]][cc[k]];
+        p[k].inv_d = s_inv[rr[k]][cc[k]]; p[k].ok = s_ok[rr[k]][cc[k]] != 0;
+    }
+    if (quad_trimmed(w[0], w[1], w[2], w[3], thresh)) return;
+    // triangles (0,1,2) and (0,2,3)
     RasTri T;
-    if (ras_setup_projected(p0, p1, p2, T)) ras_draw_tri(zbuf, T, 2 * q, znear, zfar, n, m);
-    if (ras_setup_projected(p0, p2, p3, T)) ras_draw_tri(zbuf, T, 2 * q + 1, znear, zfar, n, m);
+    if (ras_setup_projected(p[0], p[1], p[2], T)) ras_draw_tri(zbuf, T, 2 * q, znear, zfar, n, m);
+    if (ras_setup_projected(p[0], p[2], p[3], T)) ras_draw_tri(zbuf, T, 2 * q + 1, znear, zfar, n, m);
 }
 
 // ---- resolve + PredictedFrame::ReadFrame + ProjectMask + the gather of ProjectLabel -------------------
