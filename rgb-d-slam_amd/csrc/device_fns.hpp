@@ -214,23 +214,43 @@ __device__ __forceinline__ bool ras_cover(const RasTri &T, int px, int py, long 
     if (w[2] == 0 && !ras_topleft(T.X[0], T.Y[0], T.X[1], T.Y[1])) return false;
     return true;
 }
-// z-buffer pass for one triangle (already set up)
+// z-buffer pass for one triangle (already set up).  The three edge functions are affine in the pixel: they are evaluated
+// once at the corner of the bounding box and then stepped (exact 64-bit integers, so every pixel sees the value ras_cover
+// computes from scratch -- two 64-bit multiplies per edge and pixel there, one 64-bit add here).
 __device__ __forceinline__ void ras_draw_tri(unsigned long long *__restrict__ zbuf, const RasTri &T, uint32_t tri_id, float znear,
                                              float zfar, int n, int m) {
     int xmn = min(T.X[0], min(T.X[1], T.X[2])), xmx = max(T.X[0], max(T.X[1], T.X[2]));
     int ymn = min(T.Y[0], min(T.Y[1], T.Y[2])), ymx = max(T.Y[0], max(T.Y[1], T.Y[2]));
     int x0 = max(0, (xmn + 255) >> 8), x1 = min(m - 1, xmx >> 8);
     int y0 = max(0, (ymn + 255) >> 8), y1 = min(n - 1, ymx >> 8);
-    for (int py = y0; py <= y1; py++)
+    if (x0 > x1 || y0 > y1) return;
+    // edge k runs from vertex (k+1)%3 to vertex (k+2)%3 (as in ras_cover)
+    long long row[3], sx[3], sy[3];
+    bool tl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        row[k] = ras_edge(T.X[a], T.Y[a], T.X[b], T.Y[b], x0 * 256, y0 * 256);
+        sx[k] = -(long long)(T.Y[b] - T.Y[a]) * 256;          // one pixel to the right
+        sy[k] = (long long)(T.X[b] - T.X[a]) * 256;           // one pixel down
+        tl[k] = ras_topleft(T.X[a], T.Y[a], T.X[b], T.Y[b]);
+    }
+    for (int py = y0; py <= y1; py++) {
+        long long w[3] = {row[0], row[1], row[2]};
         for (int px = x0; px <= x1; px++) {
-            long long w[3];
-            if (!ras_cover(T, px, py, w)) continue;
-            double W = ((double)w[0] * T.inv_d[0] + (double)w[1] * T.inv_d[1]) + (double)w[2] * T.inv_d[2];
-            float dpx = (float)((double)T.area / W);
-            if (!(dpx >= znear) || !(dpx <= zfar)) continue;
-            unsigned long long key = ((unsigned long long)__float_as_uint(dpx) << 32) | (unsigned long long)(0xFFFFFFFFu - tri_id);
-            atomicMin(&zbuf[(size_t)py * m + px], key);
+            const bool in = !(w[0] < 0 || w[1] < 0 || w[2] < 0) && (w[0] != 0 || tl[0]) && (w[1] != 0 || tl[1]) && (w[2] != 0 || tl[2]);
+            if (in) {
+                double W = ((double)w[0] * T.inv_d[0] + (double)w[1] * T.inv_d[1]) + (double)w[2] * T.inv_d[2];
+                float dpx = (float)((double)T.area / W);
+                if (dpx >= znear && dpx <= zfar) {
+                    unsigned long long key = ((unsigned long long)__float_as_uint(dpx) << 32) | (unsigned long long)(0xFFFFFFFFu - tri_id);
+                    atomicMin(&zbuf[(size_t)py * m + px], key);
+                }
+            }
+            w[0] += sx[0]; w[1] += sx[1]; w[2] += sx[2];
         }
+        row[0] += sy[0]; row[1] += sy[1]; row[2] += sy[2];
+    }
 }
 __device__ __forceinline__ void ras_draw(unsigned long long *__restrict__ zbuf, const F3 *vtx, uint32_t tri_id,
                                          const CalibV &c, float znear, float zfar, int n, int m) {
