@@ -492,3 +492,112 @@ def test_icp_system_matches_literal_jacobian_form_in_float64(orc, pair):
     err = np.abs(got - np.array(want)) / (np.array(scale) + 1e-300)
     print("literal-Jacobian KAT: correspondence agreement %.6f, max |diff| / sum|terms| = %.3g" % (agree, err.max()))
     assert err.max() <= 1e-6
+
+
+def test_normals_match_float64_four_triangle_average(orc):
+    """Independent restatement of NormalProcess (D1/Kernel.cu:122-300) in vectorised float64 on a rough surface with
+    holes: the four triangles (down, right), (right, up), (up, left), (left, down) around a pixel, each normalised when
+    both of its neighbours have z != 0 and its cross product is not zero, averaged over the triangles that counted,
+    normalised again, negated for inverse = true; border pixels and pixels with z == 0 get zeros."""
+    rng = np.random.default_rng(11)
+    n, m = 40, 56
+    ii, jj = np.meshgrid(np.arange(n), np.arange(m), indexing="ij")
+    z = -(1.5 + 0.2 * np.sin(ii / 5.0) * np.cos(jj / 7.0) + 0.01 * rng.standard_normal((n, m)))
+    v = np.stack([(jj - 28.0) / 60.0 * -z, (ii - 20.0) / 60.0 * -z, z], -1).astype(np.float32)
+    holes = rng.random((n, m)) < 0.08
+    v[holes] = 0.0
+    for inverse in (True, False):
+        got = orc.compute_normal(v, inverse)
+        V = v.astype(np.float64)
+        want = np.zeros((n, m, 3))
+        c = V[1:-1, 1:-1]
+        dn, up, rt, lf = V[2:, 1:-1], V[:-2, 1:-1], V[1:-1, 2:], V[1:-1, :-2]
+        acc = np.zeros_like(c); cnt = np.zeros(c.shape[:2])
+        for p2, p3 in ((dn, rt), (rt, up), (up, lf), (lf, dn)):
+            cr = np.cross(p2 - c, p3 - c)
+            nn = (cr * cr).sum(-1)
+            use = (p2[..., 2] != 0) & (p3[..., 2] != 0) & (nn != 0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                acc += np.where(use[..., None], cr / np.sqrt(nn)[..., None], 0.0)
+            cnt += use
+        with np.errstate(divide="ignore", invalid="ignore"):
+            avg = acc / cnt[..., None]
+            nrm = np.sqrt((avg * avg).sum(-1))
+            res = np.where(((cnt > 0) & (nrm != 0) & (c[..., 2] != 0))[..., None], avg / nrm[..., None], 0.0)
+        want[1:-1, 1:-1] = -res if inverse else res
+        # a float32 cross product of nearly parallel edges can round to exactly zero where the float64 one does not (and
+        # the triangle then counts or not): compare where both agree on "has a normal", which must be nearly everywhere
+        has_g, has_w = np.abs(got).sum(-1) > 0, np.abs(want).sum(-1) > 0
+        assert (has_g == has_w).mean() > 0.999
+        both = has_g & has_w
+        assert both.sum() > 0.6 * n * m
+        assert np.abs(got[both] - want[both]).max() < 2e-3     # cancellation in the cross products of a 1 cm-rough surface
+        assert np.abs(got[both] - want[both]).mean() < 2e-5
+        assert not got[0].any() and not got[-1].any() and not got[:, 0].any() and not got[:, -1].any()
+
+
+def test_bump_encode_and_decode_match_float64_formulas(orc, synth):
+    """Independent float64 restatement of UpdateKernel's write (D1/Primitive.cu:285-349) and of VertexFromBumpKernel
+    (Primitive.cu:31-93) on a sparse frame (one pixel per cell, so the winner rule is not involved): cell index, the three
+    Bump words, the colour bytes, the mask; and the decoded vertex / colour / packed mask of every written cell."""
+    rng = np.random.default_rng(5)
+    N = 96
+    eq, centers = synth.plane_equations()
+    E, ctr = eq[1].astype(np.float64), centers[1].astype(np.float64)
+    res = 0.004
+    scale = 2.0 / res
+    shift = np.array([ctr @ E[3:6] - N * res / 2.0, ctr @ E[6:9] - N * res / 2.0])
+    param = np.array([E[0], E[1], E[2], E[9], scale, scale, shift[0], shift[1], E[3], E[4], E[5], E[6], E[7], E[8]], np.float32)
+    P64 = param.astype(np.float64)
+    # one point per chosen cell, well inside it, a few mm off the plane; world -> camera by a small rigid motion
+    n, m = 24, 32
+    cells = rng.choice(N * N, n * m, replace=False)
+    ci, cj = cells // N, cells % N
+    a = (ci + rng.uniform(0.15, 0.85, n * m)) * 2.0 / P64[4] + P64[6]
+    b = (cj + rng.uniform(0.15, 0.85, n * m)) * 2.0 / P64[5] + P64[7]
+    off = rng.uniform(-0.02, 0.02, n * m)
+    world = a[:, None] * P64[8:11] + b[:, None] * P64[11:14] + (P64[3] + off)[:, None] * P64[0:3]
+    Rw = synth.euler_xyz(0.02, -0.015, 0.01); tw = np.array([0.01, -0.02, 0.015])      # camera-to-world
+    cam = (world - tw) @ Rw                                                              # = R^T (p - t)
+    pose = np.eye(4); pose[:3, :3] = Rw; pose[:3, 3] = tw
+    pose_cm = pose.T.reshape(-1).astype(np.float32)                                      # column-major, as pose[0..15] is read
+    vmap = cam.reshape(n, m, 3).astype(np.float32)
+    rgbd = rng.random((n, m, 4)).astype(np.float32)
+    mask = np.full((n, m), 50, np.uint8)
+    label = np.ones((n, m), np.uint8)
+    bumps = [np.zeros((N, N, 3), np.uint16)]; rgbs = [np.zeros((N, N, 3), np.uint8)]; masks = [np.zeros((N, N), np.uint8)]
+    claims = [np.zeros((N, N), np.uint64)]
+    orc.update(bumps, rgbs, masks, [param], claims, 1, vmap, rgbd, mask, label, pose_cm)
+    # ---- encode, float64, from the float32 inputs the oracle saw ----
+    Pm = pose_cm.astype(np.float64).reshape(4, 4).T
+    pt = vmap.reshape(-1, 3).astype(np.float64) @ Pm[:3, :3].T + Pm[:3, 3]
+    err = pt @ P64[0:3] - P64[3]
+    pa = (pt @ P64[8:11] - P64[6]) * P64[4] / 2.0
+    pb = (pt @ P64[11:14] - P64[7]) * P64[5] / 2.0
+    ii, jj = np.floor(pa).astype(np.int64), np.floor(pb).astype(np.int64)
+    assert np.array_equal(ii, ci) and np.array_equal(jj, cj)
+    assert int((masks[0] == 50).sum()) == n * m and np.array_equal(np.flatnonzero(masks[0].reshape(-1) == 50), np.sort(cells))
+    want_b = np.stack([np.rint((pa - ii) * 60000.0), np.rint((pb - jj) * 60000.0), np.rint((err + 15.0) * 2000.0)], 1)
+    got_b = bumps[0][ii, jj].astype(np.float64)
+    # float32: the in-plane coordinate (~1 m, a three-term dot product: a few ulps of 1.2e-7) times scale / 2 = 250 cells per
+    # metre times 60000 counts per cell is ~2 counts per ulp; the distance word sees 2000 counts per metre: < 0.01 count
+    diff = np.abs(got_b - want_b)
+    assert diff[:, :2].max() <= 8 and diff[:, :2].mean() < 1.5 and diff[:, 2].max() <= 1 and (diff[:, 2] == 0).mean() > 0.98
+    want_c = np.rint(rgbd.reshape(-1, 4)[:, :3].astype(np.float64) * 255.0)
+    assert np.abs(rgbs[0][ii, jj].astype(np.float64) - want_c).max() <= 1 and (rgbs[0][ii, jj] == want_c).mean() > 0.99
+    # ---- decode, float64, from the stored words ----
+    v, c, mk = orc.vertex_from_bump(bumps[0], rgbs[0], masks[0], param)
+    B = bumps[0].astype(np.float64)
+    gi, gj = np.meshgrid(np.arange(N, dtype=np.float64), np.arange(N, dtype=np.float64), indexing="ij")
+    x = (gi + B[..., 0] / 60000.0) * 2.0 / P64[4] + P64[6]
+    y = (gj + B[..., 1] / 60000.0) * 2.0 / P64[5] + P64[7]
+    d = P64[3] + (B[..., 2] / 2000.0 - 15.0)
+    V = x[..., None] * P64[8:11] + y[..., None] * P64[11:14] + d[..., None] * P64[0:3]
+    w = masks[0] == 50
+    assert np.abs(v[w] - V[w]).max() < 2e-6 * 4                       # float32 evaluation of numbers of size ~2
+    assert np.abs(c[w][:, :3] - rgbs[0][w] / 255.0).max() < 1e-7 and np.all(c[w][:, 3] == 1.0)
+    assert np.abs(mk[w][:, :3] - (10.0 + V[w]) / 20.0).max() < 1e-6 and np.allclose(mk[w][:, 3], 50 / 255.0, atol=1e-7)
+    assert not v[~w].any() and not c[~w].any() and not mk[~w].any()   # empty cells decode to zeros (Primitive.cu:47-60)
+    # and the decoded points are the fused points to within the quantisation of the code: 1/60000 of a cell in the plane,
+    # half of 1/2000 m = 0.25 mm along the normal
+    assert np.abs(V[ii, jj] - pt).max() < 2.6e-4
