@@ -360,11 +360,18 @@ extern "C" int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *
 // Labels by plane membership for tiled models (test / bench harness stand-in for plane detection, like rgbdslam_seed_labels):
 // a pixel takes the FIRST plane k in [0, nb) whose equation it satisfies (|n.p - d| <= epsilon, n.n_p >= alpha) AND whose
 // N_prim x M_prim Bump image contains its cell -- so patches that tile one infinite plane get distinct labels.
-__global__ void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *__restrict__ VMap, const float *__restrict__ NMap,
-                                   PoseV P, const float *__restrict__ hist, const float *const *__restrict__ ParamTab, int nb, int N_prim,
-                                   int M_prim, float epsilon, float alpha, int n, int m) {
+// The parameters of 256 planes at a time are staged in LDS (one plane per thread: pointer, then 14 floats, all in flight
+// together); read plane by plane through two dependent wave-uniform loads each, the 256-plane scan of one pixel was a chain
+// of 512 memory round trips (138 us for a 640 x 480 frame).
+#define LBL_CHUNK (TILE_W * TILE_H)
+__global__ __launch_bounds__(TILE_W * TILE_H)
+void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *__restrict__ VMap, const float *__restrict__ NMap,
+                        PoseV P, const float *__restrict__ hist, const float *const *__restrict__ ParamTab, int nb, int N_prim,
+                        int M_prim, float epsilon, float alpha, int n, int m) {
+    __shared__ float sq[LBL_CHUNK][15];                 // 15: odd stride, the staging writes of neighbouring threads do not collide
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
-    if (i >= n || j >= m) return;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    const bool in = i < n && j < m;
     if (hist) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -372,14 +379,25 @@ __global__ void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *
         }
         P.v[12] = hist[9]; P.v[13] = hist[10]; P.v[14] = hist[11]; P.v[15] = 1.0f;
     }
-    size_t idx = (size_t)i * m + j;
+    const size_t idx = in ? (size_t)i * m + j : 0;
     uint16_t res = 0;
-    F3 nl = ld3(NMap, idx);
-    if (!is_zero3(nl)) {
-        const F3 p = xf_point(P.v, ld3(VMap, idx));
-        const F3 q = xf_dir(P.v, nl);
-        for (int k = 0; k < nb; k++) {                  // plane parameters through wave-uniform addresses
-            const float *Q = ParamTab[k];
+    const F3 nl = ld3(NMap, idx);
+    bool open = in && !is_zero3(nl);                    // still looking for its plane
+    const F3 p = xf_point(P.v, ld3(VMap, idx));
+    const F3 q = xf_dir(P.v, nl);
+    for (int base = 0; base < nb; base += LBL_CHUNK) {
+        const int cnt = min(LBL_CHUNK, nb - base);
+        __syncthreads();                                // the previous chunk has been read
+        if (tid < cnt) {
+            const float *Q = ParamTab[base + tid];
+#pragma unroll
+            for (int z = 0; z < 14; z++) sq[tid][z] = Q[z];
+        }
+        __syncthreads();
+        if (!__syncthreads_or(open)) break;             // every pixel of the tile has its label
+        for (int k = 0; k < cnt && __ballot(open); k++) {
+            if (!open) continue;
+            const float *Q = sq[k];
             // the two cheap tests first: the cell geometry (two f64 divisions) only for planes whose equation fits -- the
             // same three conditions as the oracle's, evaluated lazily
             const float ea = (q.x * Q[0] + q.y * Q[1]) + q.z * Q[2];
@@ -387,11 +405,11 @@ __global__ void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *
             if (__builtin_fabsf(err) > epsilon || ea < alpha) continue;
             UpdCell u;
             if (!update_cell(p, Q, N_prim, M_prim, u)) continue;
-            res = (uint16_t)(k + 1);
-            break;
+            res = (uint16_t)(base + k + 1);
+            open = false;
         }
     }
-    Label16[idx] = res;
+    if (in) Label16[idx] = res;
 }
 extern "C" int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float *VMap, const float *NMap,
                                          const float *pose16_host, const float *history_entry_dev, float **ParamTab, int nb_planes,
