@@ -264,6 +264,13 @@ def run_planes(args, env):
                 d = -d
             k += d
         pos = [0]
+        step_no = [0]
+        view_w2c = []
+        for R_, t_ in synth.trajectory(POOL_FRAMES, 0):
+            Pw = np.eye(4)
+            Pw[:3, :3] = R_.T
+            Pw[:3, 3] = -R_.T @ t_
+            view_w2c.append(np.ascontiguousarray(Pw.T.reshape(-1), np.float32))    # column-major 4x4
         ev = {}
 
         def step(mark=None):
@@ -284,6 +291,14 @@ def run_planes(args, env):
             shard.fuse_and_decode(pack)
             if mark:
                 mark("t3")
+            if args.planes_predict:
+                # the "raycast" half of configs[2]: the view of the frame just fused, predicted from the planes.  The view is
+                # the synthetic trajectory's pose of that frame (known to every rank without reading the tracked pose
+                # back from rank 0's device: nothing here waits for the GPU)
+                shard.predict(view_w2c[order[step_no[0] % len(order)]], n, m)
+            step_no[0] += 1
+            if mark:
+                mark("t4")
 
         for _ in range(1 + args.warmup):
             step()
@@ -313,16 +328,21 @@ def run_planes(args, env):
         tot_ms, launches = _profile(lib, ctx._h, "k_vertex_from_bump_batch", lambda: [step(mark if rank == 0 else None) for _ in range(reps)])
         stream.synchronize()
         if rank == 0:
-            acc = {"track_label_export": 0.0, "broadcast": 0.0, "fuse_decode": 0.0}
-            for q in range(0, len(marks), 4):
+            acc = {"track_label_export": 0.0, "broadcast": 0.0, "fuse_decode": 0.0, "predict_draw_merge_resolve": 0.0}
+            for q in range(0, len(marks), 5):
                 acc["track_label_export"] += marks[q][1].elapsed_time(marks[q + 1][1])
                 acc["broadcast"] += marks[q + 1][1].elapsed_time(marks[q + 2][1])
                 acc["fuse_decode"] += marks[q + 2][1].elapsed_time(marks[q + 3][1])
+                acc["predict_draw_merge_resolve"] += marks[q + 3][1].elapsed_time(marks[q + 4][1])
             phases = {k_: round(v / reps * 1e3, 1) for k_, v in acc.items()}
             phases["unit"] = "us per step on rank 0 (event pairs on its stream, second pass)"
         # "a checksum of checksums": the model after all steps, independent of how the planes were partitioned
         chk = torch.tensor([int(shard.bump.to(torch.int64).sum()) + 3 * int(shard.rgb.to(torch.int64).sum()) + 7 * int(shard.mask.to(torch.int64).sum()),
                             int((shard.mask > 10).sum())], dtype=torch.int64, device=env["coll_dev"])
+        if args.planes_predict:
+            # the last predicted view, summed over the ranks' disjoint outputs as integers: independent of the partition
+            pchk = int(shard.pred_v.view(torch.int32).to(torch.int64).sum()) + 3 * int(shard.pred_c.view(torch.int32).to(torch.int64).sum())
+            chk = torch.cat([chk, torch.tensor([pchk, int((shard.pred_v[..., 2] != 0).sum())], dtype=torch.int64, device=env["coll_dev"])])
         if world > 1:
             dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         cells = (shard.hi - shard.lo) * N * N
@@ -334,13 +354,16 @@ def run_planes(args, env):
         if rank != 0:
             ctx.close()
             return None
-        out = {"metric": "plane-partitioned Bump fusion + decode steps/sec (256 planes x 512x512, one 640x480 frame per step)",
+        out = {"metric": "plane-partitioned Bump fusion + decode%s steps/sec (256 planes x 512x512, one 640x480 frame per step)"
+                         % (" + prediction" if args.planes_predict else ""),
                "value": round(args.steps / dt, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[2]: 256 planes x 512x512 Bump cells tiled over the three planes of the synthetic room "
                                       "corner; per step rank 0 tracks one 640x480 frame, labels it (u16) and broadcasts VMap/RGBD/Mask/Label/pose "
-                                      "(%d bytes), every rank fuses it into and decodes the planes it owns" % pack.nbytes,
+                                      "(%d bytes), every rank fuses it into and decodes the planes it owns%s" % (pack.nbytes,
+                                      ", then draws them into a u64 z-buffer for the frame's view, all-reduce(MIN) of %d bytes, resolve" % (8 * n * m)
+                                      if args.planes_predict else ""),
                           "planes_per_rank": shard.hi - shard.lo, "broadcast_bytes": pack.nbytes, "backend": env["backend"],
                           "frames_resident_in_hbm": True},
                "roofline": {"bound": "hbm", "kernel": "k_vertex_from_bump_batch", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -348,7 +371,9 @@ def run_planes(args, env):
                             "algorithmic_bytes_per_launch": 54 * cells, "avg_launch_us": round(avg_ms * 1e3, 2),
                             "note": "rank 0's share: 54 B per owned Bump cell per launch"},
                "phases": phases, "cpu_baseline": None,
-               "model_checksum": int(chk[0].item()), "cells_fused": int(chk[1].item())}
+               "model_checksum": int(chk[0].item()), "cells_fused": int(chk[1].item()),
+               "prediction_checksum": int(chk[2].item()) if args.planes_predict else None,
+               "predicted_coverage": round(int(chk[3].item()) / float(n * m), 4) if args.planes_predict else None}
         rg.close()
         ctx.close()
         return out
@@ -457,6 +482,9 @@ def main():
                     help="sequences (default): the BASELINE metric, configs[1] at N=1 / configs[4] at N>1 (one sequence per GPU); "
                          "planes: configs[2], 256 planes x 512x512, rank 0 tracks + broadcasts the frame, every rank fuses + decodes "
                          "its planes; rows: configs[3], row-sharded ICP at 1920x1080 with the 27-float exchange")
+    ap.add_argument("--planes-predict", type=int, default=1,
+                    help="planes mode: 1 (default) = every step also predicts the frame's view from the planes (draw + all-reduce(MIN) + "
+                         "resolve, the raycast half of configs[2]); 0 = fusion + decode only")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer"],
                     help="rows mode: how the 27 partial sums travel (torch.distributed all-gather, or peer-mapped slots)")
     ap.add_argument("--rows", type=int, default=480)

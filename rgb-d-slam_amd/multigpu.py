@@ -243,6 +243,28 @@ class PlaneShard:
                                             self.lo, self.hi, self.N, self.N)
 
 
+    def predict(self, pose_w2c16, n, m, min_conf=1):
+        """Prediction of the view `pose_w2c16` (world-to-camera, column-major 4x4) from the planes, partitioned like the
+        fusion: this rank draws the planes it owns into its own u64 z-buffer, ONE all-reduce(MIN) merges the ranks'
+        buffers (the key is depth bits << 32 | ~triangle id: the nearest surface wins whoever drew it), and the rank
+        resolves the pixels its planes won into pred_v / pred_c (the other pixels stay untouched: the ranks' outputs are
+        disjoint)."""
+        if getattr(self, "zbuf", None) is None or self.zbuf.shape != (n, m):
+            self.zbuf = torch.full((n, m), -1, dtype=torch.int64, device="cuda")       # all ones = empty
+            self.pred_v = torch.zeros(n, m, 3, device="cuda")
+            self.pred_c = torch.zeros(n, m, 4, device="cuda")
+        if self.hi > self.lo:
+            self.ctx.planes_draw(self.zbuf, self.t_bump, self.t_rgb, self.t_mask, self.t_param, self.lo, self.hi, pose_w2c16,
+                                 self.N, self.N, n, m, min_conf=min_conf)
+        allreduce_min_u64(self.zbuf)
+        self.pred_v.zero_(); self.pred_c.zero_()          # pixels other ranks' planes won stay zero here: the outputs are disjoint
+        if self.hi > self.lo:
+            self.ctx.planes_resolve(self.zbuf, self.pred_v, self.pred_c, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
+                                    self.lo, self.hi, pose_w2c16, self.N, self.N, n, m, reset=False)
+        # every rank holds the MERGED buffer: the resolve only clears the pixels this rank's planes won, the rest is cleared here
+        self.zbuf.fill_(-1)
+
+
 _SIGN64 = -(1 << 63)
 
 

@@ -98,6 +98,10 @@ def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():
     assert one["config"]["planes_per_rank"] == 256 and two["config"]["planes_per_rank"] == 128
     assert one["cells_fused"] > 100000
     assert (one["model_checksum"], one["cells_fused"]) == (two["model_checksum"], two["cells_fused"])
+    # the view predicted from the planes: two ranks draw half of the planes each, merge the z-buffers by an unsigned minimum and
+    # resolve what their planes won -- together exactly the pixels (bits) one rank predicts from all planes
+    assert one["predicted_coverage"] > 0.9 and "prediction" in one["metric"]
+    assert (one["prediction_checksum"], one["predicted_coverage"]) == (two["prediction_checksum"], two["predicted_coverage"])
     for o in (one, two):
         assert o["roofline"]["kernel"] == "k_vertex_from_bump_batch" and 0.0 < o["roofline"]["frac"] < 1.0
         assert o["unit"] == "steps/s" and o["value"] > 0
