@@ -9,6 +9,7 @@
 // (D1/ICP.cu:50-70): the 27 sums are bit-identical to a serial restatement of the reference.
 #include "common.hpp"
 #include <string.h>
+#include <math.h>
 
 #define ICP_CHAIN_WAVES 6  // waves per chain: 12 waves per workgroup = 3 on every SIMD (10 left two SIMDs with 3 and two with 2, and the loaded pair set the pace); 640x480 has 9.4 blocks per chain -> rounds of 6 + 3.4
 #define ICP_WG_CHAINS 2    // a workgroup owns chains t and t+256 and adds their sums itself (first level of reduce<512>):
@@ -103,21 +104,24 @@ __device__ __forceinline__ void icp_pin_gather_after_prefetch(IcpCurrPx &c) {
 // re-materialised the fourteen zeros at every nesting level (5 x 14 moves per pixel), and the exits never save anything
 // unless all 64 pixels of a block fail the same test.
 __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr, const IcpCurrPx &cu, const float *intr,
-                                         float distThres, float angleThres, bool inside, IcpRow &o, int &proj) {
+                                         float distThres, float angleThres, bool inside, IcpRow &o, int &proj) {   // thresholds: icp_sq_threshold of the reference's
     const float d0 = pr.d0, d1 = pr.d1, d2 = pr.d2, n0 = pr.n0, n1 = pr.n1, n2 = pr.n2, az = pr.az;
     const unsigned int pidx = pr.pidx;
     const float i_prev = mp.ip;
     const F3 nc = cu.nc;
     const F3 s = cu.s;
+    // The two tests of searchGauss are sqrt(x) > threshold (ICP.cu:118-131).  A correctly rounded square root is monotonic, so
+    // each is the same predicate as x > T with T = the largest float whose root does not exceed the threshold -- found once
+    // on the host (icp_sq_threshold) -- and the two roots (14 instructions each) are never taken.  NaN and infinity behave
+    // alike on both sides (NaN fails both forms of the comparison, i.e. passes the test, as in the reference).
     float ex = d0 - s.x, ey = d1 - s.y, ez = d2 - s.z;
-    float dist = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+    const float dist2 = (ex * ex + ey * ey) + ez * ez;
     float x0 = nc.y * n2 - nc.z * n1;
     float x1 = (-nc.x) * n2 + nc.z * n0;
     float x2 = nc.x * n1 - nc.y * n0;
-    float ang = __builtin_sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
-    // ICP.cu:96-131: zero model normal, zero current normal, distance, angle (a NaN passes both comparisons, as there)
-    // and the sample position beyond the image (ICP.cu:222)
-    const bool reject = (int)!inside | (int)is_zero3(mp.np) | (int)is_zero3(nc) | (int)(dist > distThres) | (int)(ang > angleThres);
+    const float ang2 = (x0 * x0 + x1 * x1) + x2 * x2;
+    // ICP.cu:96-131: zero model normal, zero current normal, distance, angle; and the sample position beyond the image (ICP.cu:222)
+    const bool reject = (int)!inside | (int)is_zero3(mp.np) | (int)is_zero3(nc) | (int)(dist2 > distThres) | (int)(ang2 > angleThres);
     if (reject) return false;
 
     F3 cc = cu.cc;
@@ -256,7 +260,7 @@ struct IcpIterArgs {
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
     size_t gxp, gyp;
     const float *VMap_prev, *NMap_prev, *RGBD_prev;
-    float distThres, angleThres;
+    float distThres, angleThres;                     // icp_sq_threshold(distThres), icp_sq_threshold(angleThres): see icp_rows
     int n, m, fact;
     int grid_rows, grid_cols;                        // full 8x8-block grid (D1/ICP.cu:260-261)
     int br_lo, rows_local;                           // block-row band handled by this launch (row-sharded ICP)
@@ -720,7 +724,7 @@ struct IcpLoopArgs {
     rgbdslam_pose_block *pb;
     float *history;
     int frame_index;
-    float distThres, angleThres, thr_alpha, thr_tr;
+    float distThres, angleThres, thr_alpha, thr_tr;  // the first two: icp_sq_threshold of the caller's (icp_rows)
     int n, m;
     float intr4[4];
     IcpLoopLevel lv[3];                              // unused entries: start = ICP_LV_UNUSED
@@ -1399,6 +1403,22 @@ struct IcpMaps {
 };
 
 // One launch of k_icp_iter over block rows [br_lo, br_hi) of the level's 8x8-block grid.
+// Largest float T with sqrtf(T) <= t, so that "sqrtf(x) > t" == "x > T" for every x >= 0, NaN and infinity included
+// (icp_rows).  t < 0: every x >= 0 exceeds it (T = -1); t NaN: nothing does (T = +inf, x > inf is never true).
+static float icp_sq_threshold(float t) {
+    if (t != t) return INFINITY;
+    if (t < 0.0f) return -1.0f;
+    if (t == INFINITY) return INFINITY;
+    float T = t * t;
+    if (T == INFINITY) T = 3.402823466e+38f;
+    while (T > 0.0f && sqrtf(T) > t) T = nextafterf(T, 0.0f);
+    for (;;) {
+        const float up = nextafterf(T, INFINITY);
+        if (up == INFINITY || !(sqrtf(up) <= t)) break;
+        T = up;
+    }
+    return T;
+}
 // the gathers address the maps with 32-bit byte offsets (icp_gather): 16 bytes per pixel and the pitched gradient images
 // must stay below 4 GB -- 268 M pixels, far beyond any depth camera
 static bool icp_offsets_fit(int n, int m, size_t gxp, size_t gyp) {
@@ -1426,7 +1446,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.intr = intr; a.R = R; a.t = t;
     a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
     a.VMap_prev = mp.VMap_prev; a.NMap_prev = mp.NMap_prev; a.RGBD_prev = mp.RGB_prev;
-    a.distThres = distThres; a.angleThres = angleThres;
+    a.distThres = icp_sq_threshold(distThres); a.angleThres = icp_sq_threshold(angleThres);
     a.n = n; a.m = m; a.fact = fact; a.grid_rows = gr; a.grid_cols = gc;
     a.br_lo = br_lo; a.rows_local = br_hi - br_lo;
     long nblk = (long)a.rows_local * gc;
@@ -1515,7 +1535,7 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
         L.VMap = VMap; L.NMap = NMap; L.RGB = RGB; L.Gx = Gx; L.Gy = Gy; L.gxp = (unsigned int)gxp; L.gyp = (unsigned int)gyp;
         L.VMap_prev = VMap_prev; L.NMap_prev = NMap_prev; L.RGBD_prev = RGB_prev;
         L.block = ctx->icp_block; L.pb = pose_block; L.history = history; L.frame_index = frame_index;
-        L.distThres = prm->distThres; L.angleThres = prm->angleThres;
+        L.distThres = icp_sq_threshold(prm->distThres); L.angleThres = icp_sq_threshold(prm->angleThres);
         L.thr_alpha = prm->thres_cvg_alpha; L.thr_tr = prm->thres_cvg_tr;
         L.n = n; L.m = m;
         for (int k = 0; k < 4; k++) L.intr4[k] = ctx->calib.v[k];
