@@ -272,7 +272,7 @@ struct IcpIterArgs {
     IcpState *state;                                 // optional: gates the launch / receives the solve
     const float *pose_state;
     int do_solve, lvl, iter, max_iter;
-    float thr_alpha, thr_tr;
+    float thr_alpha, thr_tr;                         // icp_sq_threshold_lt of the caller's (icp_pose_update_wave)
     float *trace;
     long long *timing;                               // optional debug: phase time stamps (wall_clock64, 10 ns ticks)
     int *fault;                                      // optional: set to 1 when a wait gives up (rgbdslam_icp_loop_faults)
@@ -887,6 +887,19 @@ __device__ __forceinline__ float d_frob_minus_I(const float *a) {
     return __builtin_sqrtf(s);
 }
 __device__ __forceinline__ float d_norm3(const float *v) { return __builtin_sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+// the arguments of the two square roots above, for comparisons against icp_sq_threshold_lt thresholds
+__device__ __forceinline__ float d_frob_minus_I_sq(const float *a) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float v = M3(a, r, c) - (r == c ? 1.0f : 0.0f);
+            s = s + v * v;
+        }
+    return s;
+}
+__device__ __forceinline__ float d_norm3_sq(const float *v) { return (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; }
 
 // ---- 6x6 helpers (stand-ins for Eigen's determinant() and llt().solve(), same operation order as
 // the oracle's orc_det6 / orc_llt_solve6) ----------------------------------------------------------
@@ -1096,7 +1109,9 @@ __device__ __forceinline__ float icp_pose_update_wave(const IcpState *st, const 
     M3(Rinc, 1, 2) = (float)(2.0 * (q23 - q01));
     M3(Rinc, 2, 1) = (float)(2.0 * (q23 + q01));
     const float tinc[3] = {x[0], x[1], x[2]};
-    const int cvg = (iter > max_iter) || (d_frob_minus_I(Rinc) < thr_alpha && d_norm3(tinc) < thr_tr);  // RG.cpp:889
+    // RG.cpp:889, sqrt(x) < threshold as x < icp_sq_threshold_lt(threshold): the same predicate (monotonic sqrt), no root on the
+    // serial path of the iteration
+    const int cvg = (iter > max_iter) || (d_frob_minus_I_sq(Rinc) < thr_alpha && d_norm3_sq(tinc) < thr_tr);
     cvg_out = cvg;
     // row i of Rinc
     const float a0 = i == 0 ? Rinc[0] : (i == 1 ? Rinc[1] : Rinc[2]);
@@ -1419,6 +1434,24 @@ static float icp_sq_threshold(float t) {
     }
     return T;
 }
+// Smallest float L with sqrtf(L) >= t, so that "sqrtf(x) < t" == "x < L" for every x >= 0 (and NaN: false on both sides).
+// t <= 0 or NaN: never true (L = 0: no sum of squares is below it); t = +inf: true for every finite x (L = +inf).
+static float icp_sq_threshold_lt(float t) {
+    if (t != t || t <= 0.0f) return 0.0f;
+    if (t == INFINITY) return INFINITY;
+    float L = t * t;
+    if (L == INFINITY) L = 3.402823466e+38f;
+    while (sqrtf(L) < t) {                                     // up to the first float whose root reaches t
+        if (L == 3.402823466e+38f) return INFINITY;
+        L = nextafterf(L, INFINITY);
+    }
+    for (;;) {                                                 // and down while the one below still does
+        const float dn = nextafterf(L, 0.0f);
+        if (L == 0.0f || sqrtf(dn) < t) break;
+        L = dn;
+    }
+    return L;
+}
 // the gathers address the maps with 32-bit byte offsets (icp_gather): 16 bytes per pixel and the pitched gradient images
 // must stay below 4 GB -- 268 M pixels, far beyond any depth camera
 static bool icp_offsets_fit(int n, int m, size_t gxp, size_t gyp) {
@@ -1455,7 +1488,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.chains = ctx->buf_dev; a.sums = sums; a.corr = corr;
     a.seq = ++ctx->icp_epoch_base;                        // one counter for both launch forms: a stale line never matches
     a.state = state; a.pose_state = pose_state; a.do_solve = do_solve; a.lvl = lvl; a.iter = iter; a.max_iter = max_iter;
-    a.thr_alpha = thr_alpha; a.thr_tr = thr_tr; a.trace = trace;
+    a.thr_alpha = icp_sq_threshold_lt(thr_alpha); a.thr_tr = icp_sq_threshold_lt(thr_tr); a.trace = trace;
     a.timing = ctx->icp_timing_dev;
     a.first_launch = first_launch; a.final_launch = final_launch;
     for (int k = 0; k < 4; k++) a.intr4[k] = ctx->calib.v[k];
@@ -1536,7 +1569,7 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
         L.VMap_prev = VMap_prev; L.NMap_prev = NMap_prev; L.RGBD_prev = RGB_prev;
         L.block = ctx->icp_block; L.pb = pose_block; L.history = history; L.frame_index = frame_index;
         L.distThres = icp_sq_threshold(prm->distThres); L.angleThres = icp_sq_threshold(prm->angleThres);
-        L.thr_alpha = prm->thres_cvg_alpha; L.thr_tr = prm->thres_cvg_tr;
+        L.thr_alpha = icp_sq_threshold_lt(prm->thres_cvg_alpha); L.thr_tr = icp_sq_threshold_lt(prm->thres_cvg_tr);
         L.n = n; L.m = m;
         for (int k = 0; k < 4; k++) L.intr4[k] = ctx->calib.v[k];
         L.nsteps = ns;
@@ -1620,7 +1653,7 @@ extern "C" int rgbdslam_align_solve_gathered(rgbdslam_ctx *ctx, const rgbdslam_i
         return RGBDSLAM_E_ARG;
     if (!ctx->icp_state) return RGBDSLAM_E_STATE;
     KLAUNCH(ctx, k_icp_solve, dim3(1), dim3(128), ctx->icp_state, gathered_dev, parts, pose_state_dev, lvl, iter,
-            prm->max_iter[lvl], prm->thres_cvg_alpha, prm->thres_cvg_tr, trace_dev);
+            prm->max_iter[lvl], icp_sq_threshold_lt(prm->thres_cvg_alpha), icp_sq_threshold_lt(prm->thres_cvg_tr), trace_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
