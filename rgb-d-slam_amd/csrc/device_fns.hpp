@@ -162,17 +162,21 @@ struct RasTri { int X[3], Y[3]; double inv_d[3]; long long area; int order[3]; }
 
 // projection of one vertex: shared by the two triangles of a quad (k_predict_draw projects four vertices, not six)
 struct RasVert { int X, Y; double inv_d; bool ok; };
+// Branch-free: the three rejection tests are evaluated together and applied with selects at the end (an early exit per test
+// made the callers' three projections a cascade of nested branches with their results re-zeroed at every level).  A rejected
+// vertex has all fields zero as before; the arithmetic on its garbage (division by a zero depth, ...) has no side effects.
 __device__ __forceinline__ RasVert ras_project(F3 v, const CalibV &c) {
-    RasVert P; P.X = 0; P.Y = 0; P.inv_d = 0.0; P.ok = false;
-    float dk = -v.z;
-    if (!(dk >= RASTER_MIN_DEPTH)) return P;
-    float u = (v.x / dk) * c.v[0] + c.v[2];
-    float w = (v.y / dk) * c.v[1] + c.v[3];
-    if (!(__builtin_fabsf(u) <= RASTER_GUARD) || !(__builtin_fabsf(w) <= RASTER_GUARD)) return P;
-    P.X = f2i_rn(u * 256.0f);
-    P.Y = f2i_rn(w * 256.0f);
-    P.inv_d = 1.0 / (double)dk;
-    P.ok = true;
+    RasVert P;
+    const float dk = -v.z;
+    const float u = (v.x / dk) * c.v[0] + c.v[2];
+    const float w = (v.y / dk) * c.v[1] + c.v[3];
+    const bool ok = (dk >= RASTER_MIN_DEPTH) & (__builtin_fabsf(u) <= RASTER_GUARD) & (__builtin_fabsf(w) <= RASTER_GUARD);
+    const int X = f2i_rn(u * 256.0f), Y = f2i_rn(w * 256.0f);
+    const double inv_d = 1.0 / (double)dk;
+    P.X = ok ? X : 0;
+    P.Y = ok ? Y : 0;
+    P.inv_d = ok ? inv_d : 0.0;
+    P.ok = ok;
     return P;
 }
 __device__ __forceinline__ bool ras_setup_projected(const RasVert &a, const RasVert &b, const RasVert &d, RasTri &T) {

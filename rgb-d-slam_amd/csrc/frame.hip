@@ -56,7 +56,12 @@ __global__ void k_model_reseed(const rgbdslam_pose_block *__restrict__ pb, int f
 // ---- PredictedFrame::Transform + the GL draw (Frame.cpp:281-298, GP-demo.cpp:98-113) ------------------
 // one lane per quad: the four vertices are warped by P_rel in registers (TransformVertexMapKernel),
 // trimmed (QuadTrimFrameKernel, on the warped vertices like the reference) and z-buffered.
-__device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) { return is_zero3(v) ? v : xf_point(P, v); }
+__device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) {      // selects, not a branch around the nine products
+    const F3 w = xf_point(P, v);
+    const bool z = is_zero3(v);
+    F3 r; r.x = z ? v.x : w.x; r.y = z ? v.y : w.y; r.z = z ? v.z : w.z;
+    return r;
+}
 
 // grid over n x m pixels: quad (i, j) for i < n-1, j < m-1; when the tracker lost the frame the same
 // grid re-seeds the model instead (GP-demo.cpp:189-193) -- no separate launch that usually does nothing.
