@@ -52,7 +52,7 @@ PER_PX = {"k_frame_preprocess": 2 + 3 + 12 + 12 + 12 + 4 + 4,          # depth u
           "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12 + 1 + 1 + 8,   # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap; + claim pass: Label, cell mask, claim word
           "k_update<false>": 12 + 1 + 1 + 8, "k_update<true>": 12 + 16 + 1 + 1 + 10,
           "k_update_apply_preprocess": (12 + 16 + 1 + 1 + 10) + (2 + 3 + 12 + 12 + 12 + 4 + 4),   # apply pass of frame f + preprocess of f+1
-          "k_normal_segment_merge": (12 + 12 + 1 + 1) + (16 + 1 + 2 + 12 + 16 + 1 + 12 + 12),   # first growth pass + Merge
+          "k_normal_segment_merge": (1 + 1) + (16 + 1 + 2 + 12 + 16 + 1 + 12 + 12),   # first growth pass (labels in/out; normals only where unlabeled) + Merge
           "k_segment_pass_claim": (12 + 12 + 1 + 1) + (12 + 1 + 1 + 8)}                         # last growth pass + claim pass
 
 

@@ -251,7 +251,9 @@ int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bloc
 /* rgbdslam_model_normal_segment followed by rgbdslam_model_merge_claim, as three launches instead of four:
  * [first label-growth pass + Merge] -> [second pass] -> [third pass + claim pass of Graph::Update].  Merge reads no labels
  * and the growth passes read nothing Merge writes once they have a normal map of their own (NMap_seg != NMap_out), so
- * the two share a launch (GP-demo.cpp:232-249,260; Frame.cpp:242,300-333,395; RG.cu:906-912).  Needs nbPlans > 0. */
+ * the two share a launch (GP-demo.cpp:232-249,260; Frame.cpp:242,300-333,395; RG.cu:906-912).  Needs nbPlans > 0.
+ * NMap_seg is scratch of the growth passes: on return it holds the predicted frame's normal only where a pixel had no label
+ * before the first pass (the only place a pass reads it); the model's normals are NMap_out. */
 int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
                                        const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap, const float *Equations_dev,
                                        int nbPlans, float epsilon, float alpha, const float *RGBD_in, const uint8_t *Mask_in,

@@ -197,13 +197,28 @@ struct SegArgs {
     const uint8_t *in; uint8_t *out;
     const float *Eq; float epsilon, alpha;
     int n, m;
+    int lazy_normals;            // 1: NMap is scratch of the growth passes only -- written (and computed) where a pixel has no label
 };
+// The normals of the predicted frame feed nothing but the growth passes (the reference computes them in ReadFrame,
+// Frame.cpp:242, and Merge overwrites them, Frame.cpp:331), and a growth pass looks at the normal of UNLABELED pixels only --
+// about 1 % of the image in the steady state.  When NMap is the passes' private scratch (lazy_normals) the ~330 instructions
+// of the four-triangle normal are spent only there; the labels that come out are the same.
 __device__ __forceinline__ void normal_segment_tile(const SegArgs &a, const int bx, const int by) {
     const bool tracked = pb_tracked(a.pb);             // round trip shared with the pixel's own loads
     int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
     if (i >= a.n || j >= a.m) return;
     size_t idx = (size_t)i * a.m + j;
     uint8_t mine = a.in[idx];
+    if (a.lazy_normals) {
+        if (!tracked) return;
+        if (mine == 0) {
+            const F3 nl = normal_global(a.VMap, i, j, a.n, a.m, 1);
+            st3(a.NMap, idx, nl.x, nl.y, nl.z);
+            if (a.Eq) mine = segment_pixel(a.in, a.VMap, nl, a.pb->P_glob, a.Eq, a.epsilon, a.alpha, i, j, a.n, a.m);
+        }
+        a.out[idx] = mine;
+        return;
+    }
     F3 nl = normal_global(a.VMap, i, j, a.n, a.m, 1);
     if (!tracked) return;
     st3(a.NMap, idx, nl.x, nl.y, nl.z);
@@ -452,7 +467,7 @@ extern "C" int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_p
         return RGBDSLAM_E_ARG;
     if (nbPlans < 0 || nbPlans > 255 || (nbPlans > 0 && !Equations_dev)) return RGBDSLAM_E_LIMIT;
     const float *Eq = nbPlans > 0 ? Equations_dev : nullptr;
-    SegArgs p1 = {pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m};
+    SegArgs p1 = {pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m, 0};
     KLAUNCH(ctx, k_normal_segment, grid2d(n, m), block2d(), p1);
     if (Eq) {                                                    // passes 2 and 3 (D1/RG.cu:910-911)
         SegArgs p2 = p1, p3 = p1;
@@ -516,7 +531,7 @@ extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbds
     if (nbPlans <= 0 || nbPlans > 255) return RGBDSLAM_E_LIMIT;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;                   // 23-bit pixel index in the claim key
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    SegArgs p1 = {pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, epsilon, alpha, n, m};
+    SegArgs p1 = {pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, epsilon, alpha, n, m, 1};   // NMap_seg: scratch
     SegArgs p2 = p1, p3 = p1;
     p2.in = Label_swap; p2.out = Label;
     MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
