@@ -311,7 +311,8 @@ __device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArg
 
 // LDS of one workgroup of the iteration kernels
 struct IcpShared {
-    float (&part)[ICP_MAX_WAVES][27];
+    float (&part)[2][ICP_MAX_WAVES][27];   // block sums of a round; two sets, so that a round needs ONE barrier (below)
+    float (&accB)[27];                     // chain t + 256's sum on its way to wave 0
     float (&tr)[ICP_MAX_WAVES][27 * 8];
     float (&fin)[27];
     float (&solve_sh)[2];
@@ -319,13 +320,14 @@ struct IcpShared {
     float (&spose)[24];    // pose_state snapshot for the solve
 };
 #define ICP_SHARED_DECL(S)                                                       \
-    __shared__ float part_[ICP_MAX_WAVES][27];                                   \
+    __shared__ float part_[2][ICP_MAX_WAVES][27];                                \
+    __shared__ float accB_[27];                                                  \
     __shared__ __attribute__((aligned(16))) float tr_[ICP_MAX_WAVES][27 * 8];    \
     __shared__ float fin_[27];                                                   \
     __shared__ float solve_sh_[2];                                               \
     __shared__ IcpState sst_;                                                    \
     __shared__ float spose_[24];                                                 \
-    IcpShared S = {part_, tr_, fin_, solve_sh_, sst_, spose_}
+    IcpShared S = {part_, accB_, tr_, fin_, solve_sh_, sst_, spose_}
 
 // One iteration as seen by workgroup blockIdx.x.  LOOP = called from the persistent k_icp_loop: the
 // state changes while the kernel runs, so it is read and written with agent-scope atomics (plain
@@ -354,7 +356,8 @@ __device__ __forceinline__ void icp_state_copy(IcpState *d, const IcpState *s) {
 template <bool LOOP>
 __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpShared &S, IcpLoopCtl lc, const int tid, const int t,
                                               IcpModelCache &mc) {
-    float (&part)[ICP_MAX_WAVES][27] = S.part;
+    float (&part)[2][ICP_MAX_WAVES][27] = S.part;
+    float (&accB)[27] = S.accB;
     float (&tr)[ICP_MAX_WAVES][27 * 8] = S.tr;
     float (&fin)[27] = S.fin;
     float (&solve_sh)[2] = S.solve_sh;
@@ -531,26 +534,27 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
                 }
             }
             float sum = fold27(v, lane, tr[wave]);
-            if (lane < 27) part[wave][lane] = sum;
+            if (lane < 27) part[r & 1][wave][lane] = sum;
         } else if (LOOP && r == 0 && want_next) request_next();   // a wave without a block at this level may have one at the next
+        // ONE barrier per round: the block sums alternate between two sets, and the two accumulating waves pass the next
+        // round's barrier only after they have read this round's set -- nobody can overwrite it before (round r + 2)
         __syncthreads();
-        if (wv == 0 && lane < 27) {                   // waves 0 and 5: one chain each
+        if (wv == 0 && lane < 27) {                   // the first wave of each chain adds its chain's blocks in chain order
             int cnt = min(ICP_CHAIN_WAVES, chain_len - r * ICP_CHAIN_WAVES);
-            for (int w = 0; w < cnt; w++) acc += part[wave + w][lane];
+            for (int w = 0; w < cnt; w++) acc += part[r & 1][wave + w][lane];
         }
-        __syncthreads();
     }
     long long ts1 = a.timing ? wall_clock64() : 0;
     // offset 256 of reduce<512> (ICP.cu:35): chain t + chain t+256, added here instead of in the tail (a chain that does
     // not exist contributes the 0 the reference's memset leaves in its place)
-    if (wave == ICP_CHAIN_WAVES && lane < 27) part[ICP_CHAIN_WAVES][lane] = acc;
+    if (wave == ICP_CHAIN_WAVES && lane < 27) accB[lane] = acc;
     __syncthreads();
     // Publish the 27 sums to the other XCDs without an L2 write-back and without waiting for an acknowledgement: ONE
     // wave-wide agent-scope (write-through) store puts them into line icp_chain_line(t) of the chain buffer, laid out
     // like the state line of the persistent loop -- term k in slot k + k/7, and a.seq (unique per launch / step) in the
     // last slot of every 32-byte sector.  The reader checks those sequence words (below) instead of anyone waiting.
     if (wave == 0) {
-        const float out = acc + part[ICP_CHAIN_WAVES][lane < 27 ? lane : 0];
+        const float out = acc + accB[lane < 27 ? lane : 0];
         const int k = lane - (lane >> 3);             // term held by slot `lane`
         const float v = __shfl(out, k < 27 ? k : 0);
         unsigned int word = ((lane & 7) == 7) ? a.seq : __float_as_uint(v);
