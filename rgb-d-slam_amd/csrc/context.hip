@@ -20,6 +20,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->have_calib = false;
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->buf_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr; c->icp_epoch_dev = nullptr; c->icp_block = nullptr; c->icp_epoch_base = 0; c->icp_loop = 0; c->icp_line_check = 0; c->icp_timeout_ticks = 5000000;
+    { const char *e = getenv("RGBDSLAM_SEG3"); c->seg3_fused = !(e && e[0] == '0'); }
     for (int k = 0; k < RGBDSLAM_COMPAT_MAX_PLANES; k++) c->claim_slab[k] = nullptr;
     c->claim_tab_dev = nullptr; c->claim_cells = 0; c->claim_stamp = 0; c->label_swap = nullptr; c->label_swap_px = 0; c->compat_counter = nullptr;
     for (int k = 0; k < 8; k++) c->xchg_peer[k] = nullptr;

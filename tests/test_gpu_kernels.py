@@ -832,3 +832,83 @@ def test_decode_batch_ragged_sizes_and_unaligned_planes(ctx, orc, shape, skew):
         same(host(outs[0][k]), rv)
         same(host(outs[1][k]), rc)
         same(host(outs[2][k]), rk)
+
+
+@pytest.mark.parametrize("shape,nb,density", [((480, 640), 3, 0.6), ((123, 150), 100, 0.1), ((61, 64), 255, 0.02), ((9, 700), 30, 0.5)])
+def test_segment_merge_claim_one_launch(ctx, pkg, orc, pair, synth, shape, nb, density):
+    """rgbdslam_model_segment_merge_claim -- Merge, the three growth passes out of LDS and the claim pass in ONE launch --
+    against the operator sequence rgbdslam_model_normal_segment + rgbdslam_model_merge_claim (four launches) and the
+    oracle's Segment: labels, merged maps and claim words bit for bit.  Cases: the steady state (few pixels without a
+    label), sparse labels (more queued pixels per tile than lanes), more planes than the LDS table holds (64) and than
+    one staging round holds (25), ragged sizes, a strip narrower than the label halo."""
+    import ctypes as C
+    n, m = shape
+    lib = ctx.lib
+    rng = np.random.default_rng(n * m + nb)
+    crop = lambda a: np.ascontiguousarray(np.tile(a, (1, 2) + (1,) * (a.ndim - 2))[:n, :m])
+    v = crop(pair["v0"]).copy()
+    v[5:8, 20:40] = 0                                          # no vertex: such pixels never get a label
+    eq3, _ = synth.plane_equations()
+    eq = np.zeros((nb, 10), np.float32)
+    for k in range(nb):                                        # the scene's three planes, pushed away a little more each time
+        eq[k] = eq3[k % 3]
+        eq[k, 9] += np.float32(0.02 * (k // 3))
+    Rg = synth.euler_xyz(0.004, -0.003, 0.002)
+    Pg = pose16(Rg, np.array([0.002, -0.001, 0.003]))
+    nrm = orc.compute_normal(v)
+    truth = orc.seed_labels(v, nrm, Pg, eq[:3])
+    lab0 = np.where(rng.random((n, m)) < density, truth, 0).astype(np.uint8)
+    if nb > 3:                                                 # the same plane under other labels: 3, 6, ... steps further away
+        lab0 = np.where(lab0 > 0, lab0 + 3 * rng.integers(0, (nb - lab0.max()) // 3 + 1, (n, m)), 0).astype(np.uint8)
+    lab0[n // 3:n // 3 + 12, m // 4:m // 4 + 90] = 0           # a block without labels (every pixel of some tiles is queued)
+    rgbd = crop(pair["rgbd0"]).copy()
+    rgbd[..., 3][n // 2:] *= 1.02                               # a few merge branches
+    mask = rng.integers(9, 60, (n, m)).astype(np.uint8)
+    depth, rgb = crop(pair["d1"]), crop(pair["rgb1"])
+    N_prim = 128
+    params = []
+    for k in range(nb):
+        E = eq[k]
+        cpt = np.array([0.0, 0.0, -2.0]); cpt = cpt - (E[:3] @ cpt - E[9]) * E[:3]
+        sh0 = np.float32(cpt @ E[3:6] - N_prim * 0.02 / 2.0); sh1 = np.float32(cpt @ E[6:9] - N_prim * 0.02 / 2.0)
+        params.append(np.array([E[0], E[1], E[2], E[9], 100.0, 100.0, sh0, sh1, *E[3:9]], np.float32))
+    cellmask = [rng.integers(0, 40, (N_prim, N_prim)).astype(np.uint8) for _ in range(nb)]
+    pb = torch.zeros(76, dtype=torch.float32, device="cuda")
+    pb_h = np.zeros(76, np.float32)
+    pb_h[24:28] = np.array([1, 5, 0, 1], np.int32).view(np.float32)
+    pb_h[60:76] = Pg
+    pb.copy_(dev(pb_h))
+    g_v, g_eq, g_rgbd, g_mask, g_d, g_rgb = dev(v), dev(eq), dev(rgbd), dev(mask), dev(depth), dev(rgb)
+    g_m = [dev(x) for x in cellmask]
+    g_p = [dev(x) for x in params]
+    P = lambda t: C.c_void_p(t.data_ptr())
+    f = C.c_float
+    results = []
+    for fused in (False, True):
+        lab, swap = dev(lab0), torch.zeros(n, m, dtype=torch.uint8, device="cuda")
+        nseg = torch.zeros(n, m, 3, device="cuda")
+        o_rgbd, o_mask = torch.zeros(n, m, 4, device="cuda"), torch.zeros(n, m, dtype=torch.uint8, device="cuda")
+        o_v, o_n = torch.zeros(n, m, 3, device="cuda"), torch.zeros(n, m, 3, device="cuda")
+        g_k = [torch.zeros(N_prim, N_prim, dtype=torch.int64, device="cuda") for _ in range(nb)]
+        t_m, t_p, t_k = _ptr_table(g_m), _ptr_table(g_p), _ptr_table(g_k)
+        if fused:
+            rc = lib.rgbdslam_model_segment_merge_claim(ctx._h, P(pb), P(nseg), P(g_v), P(lab), P(swap), P(g_eq), nb, f(0.1), f(0.9),
+                                                        P(g_rgbd), P(g_mask), P(g_d), C.c_size_t(2 * m), P(g_rgb), P(o_rgbd), P(o_mask),
+                                                        P(o_v), P(o_n), P(t_m), P(t_p), P(t_k), C.c_uint32(7), N_prim, N_prim, n, m, 0, nb)
+            assert rc == 0
+        else:
+            rc = lib.rgbdslam_model_normal_segment(ctx._h, P(pb), P(nseg), P(g_v), P(lab), P(swap), P(g_eq), nb, f(0.1), f(0.9), n, m)
+            assert rc == 0
+            rc = lib.rgbdslam_model_merge_claim(ctx._h, P(pb), P(g_rgbd), P(g_mask), P(g_d), C.c_size_t(2 * m), P(g_rgb), P(o_rgbd),
+                                                P(o_mask), P(o_v), P(o_n), P(swap), P(t_m), P(t_p), P(t_k), C.c_uint32(7), N_prim, N_prim,
+                                                n, m, 0, nb)
+            assert rc == 0
+        ctx.synchronize()
+        results.append([host(x) for x in (swap, o_rgbd, o_mask, o_v, o_n)] + [np.stack([host(k) for k in g_k])])
+    for a, b in zip(results[1], results[0]):
+        same(a, b)
+    seg_ref = orc.segment(lab0, v, nrm, Pg, eq, 0.1, 0.9)
+    same(results[1][0], seg_ref)
+    grown = (seg_ref > 0).sum() - (lab0 > 0).sum()
+    assert grown > 0 and (seg_ref == 0).sum() > 0
+    assert (results[1][5] != 0).sum() > 0                      # claims were made
