@@ -261,6 +261,17 @@ int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_bl
                                        uint8_t *Mask_out, float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
                                        uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m, int plane_lo,
                                        int plane_hi);
+/* The same, with OffLineFrame::LoadFrame (rgbdslam_frame_preprocess) of the NEXT input frame riding on the launch:
+ * that job depends on nothing here and is hidden under this launch's own dependent steps.  The f* / gx / gy buffers must be
+ * ones nothing of the current frame reads (the host library keeps two sets of input-frame maps for this). */
+int rgbdslam_model_segment_merge_claim_preprocess(
+    rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg, const float *VMap_pred, uint8_t *Label,
+    uint8_t *Label_swap, const float *Equations_dev, int nbPlans, float epsilon, float alpha, const float *RGBD_in,
+    const uint8_t *Mask_in, const uint16_t *depth, size_t depth_pitch_bytes, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
+    float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, int N_prim,
+    int M_prim, int n, int m, int plane_lo, int plane_hi, const uint16_t *next_depth, size_t next_depth_pitch_bytes,
+    const uint8_t *next_bgr, size_t next_bgr_pitch_bytes, float *fVMap, float *fNMap, float *fRGB, float *gx, size_t gx_pitch,
+    float *gy, size_t gy_pitch);
 /* PredictedFrame::Merge + the CLAIM pass of the Graph::Update that follows it in display() (GP-demo.cpp:249-260): the
  * claim of a pixel needs only its own merged vertex and mask, so it rides on the merge launch.  Follow with
  * rgbdslam_update_apply_tracked (same stamp, same tables) to finish the update. */

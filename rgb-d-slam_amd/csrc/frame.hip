@@ -548,10 +548,15 @@ __device__ __forceinline__ void segment3_claim_tile(const SegArgs &sg, const Mer
     const uint8_t mc = (newmask >= 0) ? (uint8_t)newmask : (uint8_t)mk;
     merge_claim(mg.ca, sg.pb->P_glob, v, in ? mc : (uint8_t)0, idx, in, (int)mine);
 }
-// PredictedFrame::Merge || the three growth passes + claim: tile rows alternate between the two jobs
+// PredictedFrame::Merge || the three growth passes + claim: tile rows alternate between the two jobs.  rows2 = twice the
+// tile rows of the image; rows from there on (if the grid has them) preprocess the NEXT input frame (OffLineFrame::LoadFrame
+// of frame f+1 into buffers nothing in this launch reads): the job is independent of everything here and its ~11 us of
+// dependent steps fit under this launch's own.
 __global__ __launch_bounds__(TILE_W * TILE_H)
-void k_segment3_merge_claim(SegArgs sg, MergeArgs mg) {
-    if (blockIdx.y & 1) {
+void k_segment3_merge_claim(SegArgs sg, MergeArgs mg, PreprocessArgs pp, int rows2) {
+    if ((int)blockIdx.y >= rows2) {
+        frame_preprocess_tile(pp, blockIdx.x, (int)blockIdx.y - rows2);
+    } else if (blockIdx.y & 1) {
         mg.ca.ParamTab = nullptr;                    // the merge tiles do not claim here
         model_merge_tile(mg, blockIdx.x, (int)(blockIdx.y >> 1));
     } else {
@@ -685,14 +690,14 @@ extern "C" int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose
 // rgbdslam_model_normal_segment + rgbdslam_model_merge_claim as THREE launches instead of four: [first growth pass +
 // merge] -> [second pass] -> [third pass + claim].  NMap_seg = the normal map of the predicted frame that the growth
 // passes use; it must not be the merge's NMap_out.  Needs planes (nbPlans > 0).
-extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
-                                                  const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap,
-                                                  const float *Equations_dev, int nbPlans, float epsilon, float alpha,
-                                                  const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
-                                                  size_t depth_pitch, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
-                                                  float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
-                                                  uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m,
-                                                  int plane_lo, int plane_hi) {
+static int segment_merge_claim_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
+                                    const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap,
+                                    const float *Equations_dev, int nbPlans, float epsilon, float alpha,
+                                    const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
+                                    size_t depth_pitch, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
+                                    float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
+                                    uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m,
+                                    int plane_lo, int plane_hi, const PreprocessArgs *next) {
     if (!ctx || !pose_block_dev || !NMap_seg || !VMap_pred || !Label || !Label_swap || Label == Label_swap || !Equations_dev)
         return RGBDSLAM_E_ARG;
     if (!RGBD_in || !Mask_in || !depth || !RGB || !RGBD_out || !Mask_out || !VMap_out || !NMap_out) return RGBDSLAM_E_ARG;
@@ -713,8 +718,11 @@ extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbds
         s3.nb_eq = nbPlans;
         mg.ca = ca;
         dim3 g2 = grid2d(n, m);
-        g2.y *= 2;
-        KLAUNCH(ctx, k_segment3_merge_claim, g2, block2d(), s3, mg);
+        const int rows2 = 2 * (int)g2.y;
+        g2.y = (unsigned)(next ? 3 * (rows2 / 2) : rows2);
+        PreprocessArgs pp = {};
+        if (next) pp = *next;
+        KLAUNCH(ctx, k_segment3_merge_claim, g2, block2d(), s3, mg, pp, rows2);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -723,6 +731,36 @@ extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbds
     KLAUNCH(ctx, k_normal_segment_merge, grid2, block2d(), p1, mg);
     KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p2);
     KLAUNCH(ctx, k_segment_pass_claim, grid2d(n, m), block2d(), p3, ca, (const float *)VMap_out, (const uint8_t *)Mask_out);
+    if (next) KLAUNCH(ctx, k_frame_preprocess, grid2d(n, m), block2d(), *next);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
+                                                  const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap,
+                                                  const float *Equations_dev, int nbPlans, float epsilon, float alpha,
+                                                  const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
+                                                  size_t depth_pitch, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
+                                                  float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
+                                                  uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m,
+                                                  int plane_lo, int plane_hi) {
+    return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, nbPlans, epsilon, alpha,
+                                    RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, MaskTab, ParamTab,
+                                    ClaimTab, stamp, N_prim, M_prim, n, m, plane_lo, plane_hi, nullptr);
+}
+// The same + rgbdslam_frame_preprocess of the NEXT input frame (same n x m) into buffers that this frame does not use.
+extern "C" int rgbdslam_model_segment_merge_claim_preprocess(
+    rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg, const float *VMap_pred, uint8_t *Label,
+    uint8_t *Label_swap, const float *Equations_dev, int nbPlans, float epsilon, float alpha, const float *RGBD_in,
+    const uint8_t *Mask_in, const uint16_t *depth, size_t depth_pitch, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
+    float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim,
+    int n, int m, int plane_lo, int plane_hi, const uint16_t *next_depth, size_t next_depth_pitch, const uint8_t *next_bgr,
+    size_t next_bgr_pitch, float *fVMap, float *fNMap, float *fRGB, float *gx, size_t gx_pitch, float *gy, size_t gy_pitch) {
+    if (!ctx || !next_depth || !next_bgr || !fVMap || !fNMap || !fRGB || !gx || !gy || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    if (next_depth_pitch < 2 * (size_t)m || next_bgr_pitch < 3 * (size_t)m || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m)
+        return RGBDSLAM_E_ARG;
+    if (fRGB == RGB || fVMap == VMap_pred || fVMap == VMap_out || fNMap == NMap_out || fNMap == NMap_seg) return RGBDSLAM_E_ARG;
+    PreprocessArgs pp = {next_depth, next_depth_pitch, next_bgr, next_bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, nbPlans, epsilon, alpha,
+                                    RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, MaskTab, ParamTab,
+                                    ClaimTab, stamp, N_prim, M_prim, n, m, plane_lo, plane_hi, &pp);
 }

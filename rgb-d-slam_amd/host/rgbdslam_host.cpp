@@ -233,6 +233,7 @@ void OffLineFrame::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host
     size_t P = (size_t)_n * _m;
     begin_load();
     hipStream_t s = _load_stream ? _load_stream : ctx_stream(_ctx);
+    if (!_depth_dev_test[_cur].p) { _depth_dev_test[_cur].alloc(P); _color_dev_test[_cur].alloc(3 * P); }   // (after a set switch)
     // GpuMat::upload x2 (Frame.cpp:56-60)
     hip_check(hipMemcpyAsync(_depth_dev_test[_cur].p, depth_host, 2 * P, hipMemcpyHostToDevice, s), "upload depth");
     hip_check(hipMemcpyAsync(_color_dev_test[_cur].p, bgr_host, 3 * P, hipMemcpyHostToDevice, s), "upload colour");
@@ -260,15 +261,25 @@ void OffLineFrame::LoadFrame(const std::string &filename_depth, const std::strin
 void OffLineFrame::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
     const bool done = _pre.valid && !_load_stream && _pre.depth == depth_dev && _pre.depth_pitch == depth_pitch && _pre.bgr == bgr_dev &&
                       _pre.bgr_pitch == bgr_pitch;
+    const bool swap_sets = done && _pre.other;
     _pre.valid = false;
     begin_load();
+    if (swap_sets) _cur ^= 1;                         // the frame's maps are in the other set already
     _depth_cur[_cur] = depth_dev;
     _depth_pitch[_cur] = depth_pitch;
     if (!done) preprocess(bgr_dev, bgr_pitch);
 }
 
-void OffLineFrame::MarkPreprocessed(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+void OffLineFrame::MarkPreprocessed(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch, bool other_set) {
     _pre.depth = depth_dev; _pre.depth_pitch = depth_pitch; _pre.bgr = bgr_dev; _pre.bgr_pitch = bgr_pitch; _pre.valid = true;
+    _pre.other = other_set;
+}
+void OffLineFrame::PrepareOtherSet() {
+    if (_load_stream) throw Error("PrepareOtherSet: the load stream owns the second buffer set", RGBDSLAM_E_STATE);
+    const int o = _cur ^ 1;
+    const size_t P = (size_t)_n * _m;
+    if (!_VMap_dev[o].p) { _VMap_dev[o].alloc(3 * P); _NMap_dev[o].alloc(3 * P); _RGB_dev[o].alloc(3 * P); }
+    if (!_Gx[o].p) { _Gx[o].alloc(P); _Gy[o].alloc(P); }
 }
 
 void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
@@ -388,8 +399,22 @@ void PredictedFrame::NormalSegmentFused(const rgbdslam_pose_block *pb, float *Eq
                                         0.1f, 0.9f, _n, _m), "model_normal_segment");
 }
 void PredictedFrame::SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans, OffLineFrame *frame,
-                                            const UpdateTables &claim) {
+                                            const UpdateTables &claim, const uint16_t *next_depth, size_t next_depth_pitch,
+                                            const uint8_t *next_bgr, size_t next_bgr_pitch) {
     if (!_NMap_seg.p) _NMap_seg.alloc(3 * (size_t)_n * _m);   // normals of the predicted frame for the growth passes (Merge owns _NMap_dev)
+    if (next_depth) {
+        frame->PrepareOtherSet();
+        const size_t gp = 4 * (size_t)_m;
+        check(rgbdslam_model_segment_merge_claim_preprocess(
+                  _ctx, pb, _NMap_seg.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans, 0.1f, 0.9f, _RGB_alt.p,
+                  _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(), _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p,
+                  claim.Mask, claim.Param, claim.Claim, claim.stamp, claim.N_prim, claim.M_prim, _n, _m, claim.plane_lo, claim.plane_hi,
+                  next_depth, next_depth_pitch, next_bgr, next_bgr_pitch, frame->otherVMap(), frame->otherNMap(), frame->otherRGB(),
+                  frame->otherGx(), gp, frame->otherGy(), gp),
+              "model_segment_merge_claim + next LoadFrame");
+        frame->MarkPreprocessed(next_depth, next_depth_pitch, next_bgr, next_bgr_pitch, true);
+        return;
+    }
     check(rgbdslam_model_segment_merge_claim(_ctx, pb, _NMap_seg.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans, 0.1f,
                                              0.9f, _RGB_alt.p, _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(),
                                              _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p, claim.Mask, claim.Param, claim.Claim,
@@ -1033,18 +1058,27 @@ int RG::StepAsync() {
     _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
     UpdateTables upd;
     const bool claim_in_merge = !ov && _graph->begin_update(&upd);
+    // when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides on a launch of this frame
+    const bool next_rides = claim_in_merge && _next_hint.valid && !ovl && _frame->has_gradients() && !_frame->bilateral();
+    bool next_done = false;
     if (claim_in_merge && _nbPlan > 0) {
-        // Frame.cpp:242 + 395, GP-demo.cpp:249 and the claim pass of :260 in three launches
-        _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd);
+        // Frame.cpp:242 + 395, GP-demo.cpp:249 and the claim pass of :260 in one launch
+        if (next_rides && _next_on_merge) {
+            _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd, _next_hint.depth,
+                                                     _next_hint.depth_pitch, _next_hint.bgr, _next_hint.bgr_pitch);
+            next_done = true;
+        } else {
+            _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd);
+        }
     } else {
         _predicted_frame->NormalSegmentFused(_pb_dev, _Equations_dev.p, _nbPlan);   // Frame.cpp:242 + 395
         _predicted_frame->MergeFused(_pb_dev, _frame, claim_in_merge ? &upd : nullptr);  // GP-demo.cpp:249 (+ claim pass of :260)
     }
     if (ovl) _frame->release(main);                                                 // last reader of this frame's buffer set
     if (!ov) {
-        // GP-demo.cpp:260; when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides along:
-        // every reader of this frame's maps has been enqueued, so the same buffers take the next frame's
-        if (claim_in_merge && _next_hint.valid && !ovl && _frame->has_gradients() && !_frame->bilateral())
+        // GP-demo.cpp:260; the next frame's LoadFrame rides here if it has not yet: every reader of this frame's maps
+        // has been enqueued, so the same buffers take the next frame's
+        if (next_rides && !next_done)
             _graph->ApplyTrackedAndPreprocess(_predicted_frame, _pb_dev, upd, _frame, _next_hint.depth, _next_hint.depth_pitch,
                                               _next_hint.bgr, _next_hint.bgr_pitch);
         else if (claim_in_merge) _graph->ApplyTracked(_predicted_frame, _pb_dev, upd);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdexcept>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -106,7 +107,16 @@ public:
     void LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
     // The maps of the frame (depth_dev, bgr_dev) were already computed into this object's buffers by a launch the caller
     // enqueued (rgbdslam_update_apply_tracked_preprocess): the LoadFrameDevice of exactly that frame launches nothing.
-    void MarkPreprocessed(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
+    // other_set: they were computed into the OTHER buffer set (other_*(), below), which that LoadFrameDevice switches to.
+    void MarkPreprocessed(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch, bool other_set = false);
+    // The buffer set the current frame does NOT use (allocated on first use; no load stream attached): a launch that still
+    // reads the current frame's maps can preprocess the next frame into it (rgbdslam_model_segment_merge_claim_preprocess).
+    void PrepareOtherSet();
+    float *otherVMap() { return _VMap_dev[_cur ^ 1].p; }
+    float *otherNMap() { return _NMap_dev[_cur ^ 1].p; }
+    float *otherRGB() { return _RGB_dev[_cur ^ 1].p; }
+    float *otherGx() { return _Gx[_cur ^ 1].p; }
+    float *otherGy() { return _Gy[_cur ^ 1].p; }
     // fused pipeline: with gradients enabled, LoadFrame* runs rgbdslam_frame_preprocess (one kernel for
     // Frame.cpp:65-71 + RG.cpp:807-810) and the tracker skips its own Sobel pass
     void EnableGradients(bool on);
@@ -141,7 +151,7 @@ private:
     hipEvent_t _ready[2] = {nullptr, nullptr}, _free[2] = {nullptr, nullptr};
     bool _free_recorded[2] = {false, false};
     bool _loaded_once = false;
-    struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false; } _pre;
+    struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false, other = false; } _pre;
 };
 
 // ---- D1/Frame.h:188-282 -----------------------------------------------------------------------
@@ -162,7 +172,10 @@ public:
     void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
     // claim != null: the claim pass of the Graph::Update that follows rides on the merge launch
     // NormalSegmentFused + MergeFused(claim) in three launches (rgbdslam_model_segment_merge_claim); needs planes
-    void SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans, OffLineFrame *frame, const UpdateTables &claim);
+    // next_depth != nullptr: the preprocessing of that next device frame rides on the launch (into frame's other buffer set)
+    void SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans, OffLineFrame *frame, const UpdateTables &claim,
+                                const uint16_t *next_depth = nullptr, size_t next_depth_pitch = 0, const uint8_t *next_bgr = nullptr,
+                                size_t next_bgr_pitch = 0);
     void MergeFused(const rgbdslam_pose_block *pb, OffLineFrame *frame, const struct UpdateTables *claim = nullptr);
     float *getVMap() { return _VMap_dev.p; }
     float *getNMap() { return _NMap_dev.p; }
@@ -310,6 +323,8 @@ public:
     int last_level_iterations = 0;   // packed per level, 8 bits each (device loop only)
     rgbdslam_ctx *ctx() { return _ctx; }
     struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false; } _next_hint;
+    // where the hinted next frame is preprocessed: on the merge launch (default) or on the apply launch (RGBDSLAM_NEXT_ON_APPLY=1)
+    bool _next_on_merge = getenv("RGBDSLAM_NEXT_ON_APPLY") == nullptr;
     std::vector<float> _Equations, _Centers;
     DevBuf<float> _Equations_dev;
 private:
