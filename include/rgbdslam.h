@@ -237,6 +237,24 @@ int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bl
                             * Mask_in are then written) -- GP-demo.cpp:189-193 without an extra launch */
                            const float *frame_VMap, const float *frame_NMap, const float *frame_RGB,
                            const uint16_t *depth, size_t depth_pitch_bytes, float *NMap_reseed);
+/* The same, with the APPLY pass of the PREVIOUS frame's Graph::Update riding on the draw launch (a caller that enqueues a
+ * recorded sequence may defer that pass by one frame: it reads the model the previous frame left -- VMap_in, RGBD_in, Mask_in,
+ * Label_in -- and is posed and gated by that frame's immutable history entry, rgbdslam_track_frame's history row). */
+int rgbdslam_model_predict_apply(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,
+                                 const float *VMap_in, const float *RGBD_in, const uint8_t *Mask_in,
+                                 const uint8_t *Label_in, uint64_t *zbuf, float *VMap_out, float *RGBD_out,
+                                 uint8_t *Mask_out, uint8_t *Label_out, float thresh, float znear, float zfar,
+                                 int n, int m, const float *frame_VMap, const float *frame_NMap,
+                                 const float *frame_RGB, const uint16_t *depth, size_t depth_pitch_bytes,
+                                 float *NMap_reseed, const float *prev_history_entry_dev, uint16_t **BumpTab,
+                                 uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                 uint32_t prev_stamp, int N_prim, int M_prim, int plane_lo, int plane_hi);
+/* The apply pass alone, posed and gated by a history entry (what a deferred apply pass becomes when no next frame comes). */
+int rgbdslam_update_apply_from_history(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab,
+                                       uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                       uint32_t stamp, const float *VMap, const float *RGBD, const uint8_t *Mask,
+                                       const uint8_t *Label, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                       int plane_hi);
 /* ComputeNormal of ReadFrame (Frame.cpp:242) + Segment_cu (Frame.cpp:395).  The result is left in
  * Label_swap (one pass when nbPlans == 0, three otherwise: always an odd number of swaps). */
 int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev,

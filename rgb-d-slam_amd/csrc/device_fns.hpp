@@ -501,3 +501,102 @@ __device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, c
     s = s + rows[0] * -1.0f; s = s + rows[1] * 0.0f; s = s + rows[2] * 1.0f;
     *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
 }
+
+// ---- D1/Primitive.cu:267-357 UpdateKernel under the winner rule: one tile ---------------------------
+// The per-pixel work is a chain of dependent gathers (label -> plane tables -> cell mask -> claim word -> stores).
+// A wavefront is 64 consecutive pixels of one image row and almost always sees ONE label: then the plane's table
+// entries and its 14 parameters are fetched once per wave through a wave-uniform address (scalar loads) instead of
+// once per lane, which takes two vector-memory round trips out of the chain.
+struct UpdateArgs {
+    uint16_t *const *BumpTab; uint8_t *const *RGBTab; uint8_t *const *MaskTab; float *const *ParamTab;
+    unsigned long long *const *ClaimTab;
+    uint32_t stamp;
+    const float *VMap, *RGBD; const uint8_t *Mask, *Label;
+    const uint16_t *Label16;                          // non-null: 16-bit labels (models of more than 255 planes), Label unused
+    PoseV P;
+    const rgbdslam_pose_block *pb;
+    const float *hist;
+    int N_prim, M_prim, n, m, plane_lo, plane_hi;
+};
+// one 64x4 tile (bx, by) of UpdateKernel; APPLY = second pass of the winner rule
+template <bool APPLY>
+__device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, const int by) {
+    uint16_t *const *__restrict__ BumpTab = a.BumpTab; uint8_t *const *__restrict__ RGBTab = a.RGBTab;
+    uint8_t *const *__restrict__ MaskTab = a.MaskTab; float *const *__restrict__ ParamTab = a.ParamTab;
+    unsigned long long *const *__restrict__ ClaimTab = a.ClaimTab;
+    const uint32_t stamp = a.stamp;
+    const float *__restrict__ VMap = a.VMap, *__restrict__ RGBD = a.RGBD;
+    const uint8_t *__restrict__ Mask = a.Mask, *__restrict__ Label = a.Label;
+    const uint16_t *__restrict__ Label16 = a.Label16;
+    PoseV P = a.P;
+    const rgbdslam_pose_block *__restrict__ pb = a.pb;
+    const float *__restrict__ hist = a.hist;
+    const int N_prim = a.N_prim, M_prim = a.M_prim, n = a.n, m = a.m, plane_lo = a.plane_lo, plane_hi = a.plane_hi;
+    if (pb) {                                         // fused pipeline: pose from the device block, gated on it
+        if (pb->status[0] != 1) return;
+#pragma unroll
+        for (int k = 0; k < 16; k++) P.v[k] = pb->P_glob[k];
+    } else if (hist) {                                // the frame's immutable history entry: poseR(9) poset(3) tracked ...
+        if (hist[12] != 1.0f) return;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            P.v[4 * c] = hist[3 * c]; P.v[4 * c + 1] = hist[3 * c + 1]; P.v[4 * c + 2] = hist[3 * c + 2]; P.v[4 * c + 3] = 0.0f;
+        }
+        P.v[12] = hist[9]; P.v[13] = hist[10]; P.v[14] = hist[11]; P.v[15] = 1.0f;
+    }
+    int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
+    const bool in = i < n && j < m;
+    const size_t idx = in ? (size_t)i * m + j : 0;
+    int L = in ? (Label16 ? (int)Label16[idx] : (int)Label[idx]) - 1 : -1;
+    const bool valid = L >= 0 && L >= plane_lo && L < plane_hi;
+    const unsigned long long vmask = __ballot(valid);
+    if (!vmask) return;
+    const int L0 = __builtin_amdgcn_readfirstlane(__shfl(L, (int)__builtin_ctzll(vmask)));
+    const bool one_plane = __ballot(valid && L != L0) == 0ull;
+    if (!valid) return;
+    const uint8_t mc = Mask[idx];
+    const F3 p = xf_point(P.v, ld3(VMap, idx));
+    UpdCell u;
+    uint8_t *maskb;
+    unsigned long long *claimb;
+    uint16_t *bumpb;
+    uint8_t *rgbb;
+    if (one_plane) {                                  // wave-uniform plane: table entries and parameters via uniform addresses
+        const float *Q = ParamTab[L0];
+        float q[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = Q[k];
+        maskb = MaskTab[L0]; claimb = ClaimTab[L0]; bumpb = BumpTab[L0]; rgbb = RGBTab[L0];
+        if (!update_cell(p, q, N_prim, M_prim, u)) return;
+        u.L = L0;
+    } else {
+        if (!update_cell(p, ParamTab[L], N_prim, M_prim, u)) return;
+        u.L = L;
+        maskb = MaskTab[L]; claimb = ClaimTab[L]; bumpb = BumpTab[L]; rgbb = RGBTab[L];
+    }
+    uint8_t *cellmask = maskb + u.cell;
+    unsigned long long *slot = claimb + u.cell;
+    const uint8_t mref = *cellmask;
+    unsigned long long owner = 0ull;
+    if (APPLY) owner = *slot;                         // independent of the mask test: both gathers are in flight together
+    bool erode = (mc < 10 && mref != 1);                                      // Primitive.cu:313
+    if (!erode && !(mc > mref)) return;                                       // Primitive.cu:341
+    unsigned long long key = claim_key(stamp, !erode, erode ? (uint8_t)0 : mc, (uint32_t)idx);
+    if (!APPLY) { atomicMax(slot, key); return; }
+    if (owner != key) return;
+    uint16_t *B = bumpb + 3 * (size_t)u.cell;
+    uint8_t *C = rgbb + 3 * (size_t)u.cell;
+    if (erode) {
+        if (mref > 11) { *cellmask = (uint8_t)(mref - 1); }
+        else { *cellmask = 10; B[0] = 0; B[1] = 0; B[2] = 0; C[0] = 0; C[1] = 0; C[2] = 0; }
+    } else {
+        float4 col = *(const float4 *)(RGBD + 4 * idx);
+        B[0] = (uint16_t)f2i_rn((float)((double)u.sa * 60000.0));             // Primitive.cu:342-344
+        B[1] = (uint16_t)f2i_rn((float)((double)u.sb * 60000.0));
+        B[2] = (uint16_t)f2i_rn((float)(((double)u.err + 15.0) * 2000.0));
+        C[0] = (uint8_t)f2i_rn((float)((double)col.x * 255.0));
+        C[1] = (uint8_t)f2i_rn((float)((double)col.y * 255.0));
+        C[2] = (uint8_t)f2i_rn((float)((double)col.z * 255.0));
+        *cellmask = mc;
+    }
+}

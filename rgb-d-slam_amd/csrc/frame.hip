@@ -63,8 +63,7 @@ __device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) {      // select
     return r;
 }
 
-// grid over n x m pixels: quad (i, j) for i < n-1, j < m-1; when the tracker lost the frame the same
-// grid re-seeds the model instead (GP-demo.cpp:189-193) -- no separate launch that usually does nothing.
+// grid over n x m pixels: quad (i, j) for i < n-1, j < m-1
 // The kernel is VALU-issue bound (822 instructions per wave at 1920 x 1080 = 43 us of issue time, 43.5 us measured; the
 // z-buffer atomics are ~1 per pixel and do not show), so a vertex is warped and projected ONCE per workgroup, not once per
 // quad that uses it: the 65 x 5 vertices of a 64 x 4 quad tile go through LDS (two f32 divisions, one f64 reciprocal and
@@ -82,7 +81,11 @@ __device__ __forceinline__ PdVert pd_vertex(const float *P, const CalibV &c, F3 
 __global__ __launch_bounds__(TILE_W * TILE_H)
 void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
                     unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
-                    ReseedArgs rs, int n, int m) {
+                    UpdateArgs upd, int rows_draw, int n, int m) {
+    // Tile rows from rows_draw on (if the grid has them): the APPLY pass of the PREVIOUS frame's Graph::Update, deferred by
+    // the caller (posed by that frame's history entry).  It reads what this launch reads -- the model the previous frame
+    // left -- and the planes; nothing in this launch writes either.
+    if ((int)blockIdx.y >= rows_draw) { update_tile<true>(upd, blockIdx.x, (int)blockIdx.y - rows_draw); return; }
     // structure of arrays, one word per lane and field: no bank conflicts
     __shared__ float s_v[3][PD_ROWS][PD_COLS];
     __shared__ int s_xy[2][PD_ROWS][PD_COLS];
@@ -103,10 +106,7 @@ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__r
     F3 v1 = ld3(VMap, ex1 ? (size_t)i * m + j : 0);
     F3 v2 = ld3(VMap, ex2 ? (size_t)(i0 + r2) * m + (j0 + c2) : 0);
     pin_loaded(v1); pin_loaded(v2);
-    if (!tracked) {
-        if (rs.fV && i < n && j < m) reseed_pixel(rs, c, i, j, n, m);
-        return;
-    }
+    if (!tracked) return;                             // (the resolve launch re-seeds the model)
     {
         const PdVert a = pd_vertex(P, c, v1, ex1);
         s_v[0][threadIdx.y][threadIdx.x] = a.v.x; s_v[1][threadIdx.y][threadIdx.x] = a.v.y; s_v[2][threadIdx.y][threadIdx.x] = a.v.z;
@@ -147,14 +147,19 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
                                   const float *__restrict__ RGBD_in, const uint8_t *__restrict__ Mask_in,
                                   const uint8_t *__restrict__ Label_in, unsigned long long *__restrict__ zbuf,
                                   float *__restrict__ VMap_out, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
-                                  uint8_t *__restrict__ Label_out, CalibV c, int n, int m) {
+                                  uint8_t *__restrict__ Label_out, CalibV c, ReseedArgs rs, int n, int m) {
     const bool tracked = pb_tracked(pb);               // round trip shared with the z-buffer word (see k_predict_draw)
     int px = blockIdx.x * TILE_W + threadIdx.x, py = blockIdx.y * TILE_H + threadIdx.y;
     if (py >= n || px >= m) return;
     size_t p = (size_t)py * m + px;
     unsigned long long key = zbuf[p];
     asm volatile("" : "+v"(key));
-    if (!tracked) return;
+    // when the tracker lost the frame this grid re-seeds the model (set "in") instead (GP-demo.cpp:189-193) -- no separate
+    // launch that usually does nothing; nothing was drawn, the z-buffer is still clear
+    if (!tracked) {
+        if (rs.fV) reseed_pixel(rs, c, py, px, n, m);
+        return;
+    }
     float4 tex; tex.x = tex.y = tex.z = tex.w = 0.0f;
     if (key != ZBUF_EMPTY) {
         zbuf[p] = ZBUF_EMPTY;
@@ -612,11 +617,12 @@ extern "C" int rgbdslam_model_reseed(rgbdslam_ctx *ctx, const rgbdslam_pose_bloc
     return 0;
 }
 
-extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
-                                      const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
-                                      float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
-                                      float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
-                                      const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed) {
+static int model_predict_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
+                              const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
+                              float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
+                              float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
+                              const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
+                              const UpdateArgs *apply) {
     if (!ctx || !pose_block_dev || !VMap_in || !RGBD_in || !Mask_in || !Label_in || !zbuf || !VMap_out || !RGBD_out ||
         !Mask_out || !Label_out)
         return RGBDSLAM_E_ARG;
@@ -628,12 +634,44 @@ extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_blo
     if (frame_VMap && (!frame_NMap || !frame_RGB || !depth || !NMap_reseed || depth_pitch < 2 * (size_t)m)) return RGBDSLAM_E_ARG;
     ReseedArgs rs = {frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, const_cast<float *>(VMap_in), NMap_reseed,
                      const_cast<float *>(RGBD_in), const_cast<uint8_t *>(Mask_in)};
-    KLAUNCH(ctx, k_predict_draw, grid2d(n, m), block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
-            ctx->calib, znear, zfar, rs, n, m);
+    dim3 gd = grid2d(n, m);
+    const int rows_draw = (int)gd.y;
+    UpdateArgs upd = {};
+    if (apply) { upd = *apply; gd.y *= 2; }
+    KLAUNCH(ctx, k_predict_draw, gd, block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
+            ctx->calib, znear, zfar, upd, rows_draw, n, m);
     KLAUNCH(ctx, k_predict_resolve, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
-            (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, n, m);
+            (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
+                                      const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
+                                      float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
+                                      float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
+                                      const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed) {
+    return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in, zbuf, VMap_out, RGBD_out, Mask_out, Label_out,
+                              thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed, nullptr);
+}
+// The same + the APPLY pass of the PREVIOUS frame's Graph::Update (rgbdslam_update_apply_from_history on VMap_in, RGBD_in,
+// Mask_in, Label_in -- the model that frame left), riding on the draw launch.
+extern "C" int rgbdslam_model_predict_apply(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
+                                            const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
+                                            float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
+                                            float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
+                                            const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
+                                            const float *prev_history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
+                                            uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t prev_stamp,
+                                            int N_prim, int M_prim, int plane_lo, int plane_hi) {
+    if (!prev_history_entry_dev || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab) return RGBDSLAM_E_ARG;
+    if (N_prim <= 0 || M_prim <= 0 || prev_stamp == 0) return RGBDSLAM_E_ARG;
+    if ((size_t)(n > 0 ? n : 0) * (size_t)(m > 0 ? m : 0) > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
+    PoseV P;
+    for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, prev_stamp, VMap_in, RGBD_in, Mask_in, Label_in,
+                    nullptr, P, nullptr, prev_history_entry_dev, N_prim, M_prim, n, m, plane_lo, plane_hi};
+    return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in, zbuf, VMap_out, RGBD_out, Mask_out, Label_out,
+                              thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed, &a);
 }
 
 extern "C" int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap,

@@ -386,8 +386,19 @@ void PredictedFrame::ReseedFused(const rgbdslam_pose_block *pb, int force, OffLi
     check(rgbdslam_model_reseed(_ctx, pb, force, frame->getVMap(), frame->getNMap(), frame->getRGB(), frame->depth(),
                                 frame->depth_pitch(), _VMap_dev.p, _NMap_dev.p, _RGB_dev.p, _Mask_dev, _n, _m), "model_reseed");
 }
-void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *frame) {
+void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *frame,
+                                  const UpdateTables *prev_apply, const float *prev_history_entry) {
     // frame != null: a lost frame re-seeds the model inside the same launch (Cpy + InitMask, GP-demo.cpp:190-191)
+    if (prev_apply) {
+        check(rgbdslam_model_predict_apply(_ctx, pb, _VMap_dev.p, _RGB_dev.p, _Mask_dev, _Label_dev, _zbuf.p, _VMap_alt.p, _RGB_alt.p,
+                                           _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m, frame ? frame->getVMap() : nullptr,
+                                           frame ? frame->getNMap() : nullptr, frame ? frame->getRGB() : nullptr,
+                                           frame ? frame->depth() : nullptr, frame ? frame->depth_pitch() : 0, _NMap_dev.p,
+                                           prev_history_entry, prev_apply->Bump, prev_apply->RGB, prev_apply->Mask, prev_apply->Param,
+                                           prev_apply->Claim, prev_apply->stamp, prev_apply->N_prim, prev_apply->M_prim,
+                                           prev_apply->plane_lo, prev_apply->plane_hi), "model_predict + previous Update_cu (apply)");
+        return;
+    }
     check(rgbdslam_model_predict(_ctx, pb, _VMap_dev.p, _RGB_dev.p, _Mask_dev, _Label_dev, _zbuf.p, _VMap_alt.p, _RGB_alt.p,
                                  _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m, frame ? frame->getVMap() : nullptr,
                                  frame ? frame->getNMap() : nullptr, frame ? frame->getRGB() : nullptr,
@@ -1055,7 +1066,12 @@ int RG::StepAsync() {
     // the previous frame's Bump update (other stream) reads the model this frame is about to rewrite
     if (ov && _update_pending) hip_check(hipStreamWaitEvent(main, _ev_updated, 0), "wait for the previous update");
     // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
-    _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
+    if (_deferred.valid) {                                                          // the previous frame's apply pass rides along
+        _deferred.valid = false;
+        _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame, &_deferred.t, _deferred.hist);
+    } else {
+        _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
+    }
     UpdateTables upd;
     const bool claim_in_merge = !ov && _graph->begin_update(&upd);
     // when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides on a launch of this frame
@@ -1081,6 +1097,11 @@ int RG::StepAsync() {
         if (next_rides && !next_done)
             _graph->ApplyTrackedAndPreprocess(_predicted_frame, _pb_dev, upd, _frame, _next_hint.depth, _next_hint.depth_pitch,
                                               _next_hint.bgr, _next_hint.bgr_pitch);
+        else if (claim_in_merge && _defer_apply && _defer_apply_enabled && _next_hint.valid) {
+            _deferred.t = upd;                                                      // -> the next frame's draw launch
+            _deferred.hist = _history_dev.p + 16 * (size_t)slot;
+            _deferred.valid = true;
+        }
         else if (claim_in_merge) _graph->ApplyTracked(_predicted_frame, _pb_dev, upd);
     } else {
         if (_graph->_nodes.size() != 0) {
@@ -1102,7 +1123,18 @@ int RG::StepAsync() {
     return first ? 2 : 1;
 }
 
+void RG::FlushDeferredApply() {
+    if (!_deferred.valid) return;
+    _deferred.valid = false;
+    const UpdateTables &t = _deferred.t;
+    check(rgbdslam_update_apply_from_history(_ctx, _deferred.hist, t.Bump, t.RGB, t.Mask, t.Param, t.Claim, t.stamp,
+                                             _predicted_frame->getVMap(), _predicted_frame->getRGB(), _predicted_frame->_Mask_dev,
+                                             _predicted_frame->_Label_dev, t.N_prim, t.M_prim, _predicted_frame->_n, _predicted_frame->_m,
+                                             t.plane_lo, t.plane_hi), "Update_cu (deferred apply)");
+}
+
 void RG::SyncAll() {
+    FlushDeferredApply();
     if (_load_stream) hip_check(hipStreamSynchronize(_load_stream), "sync load stream");
     check(rgbdslam_synchronize(_ctx), "synchronize");
     if (_update_stream) hip_check(hipStreamSynchronize(_update_stream), "sync update stream");
@@ -1110,6 +1142,7 @@ void RG::SyncAll() {
 }
 
 int RG::Sync() {
+    FlushDeferredApply();
     hipStream_t s = ctx_stream(_ctx);
     hip_check(hipMemcpyAsync(_pb_host, _pb_dev, sizeof(rgbdslam_pose_block), hipMemcpyDeviceToHost, s), "pose block download");
     int lo = _history_synced, hi = frames_done;
@@ -1313,8 +1346,10 @@ int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, 
         for (int k = 0; k < count; k++) {
             r->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
             if (k + 1 < count) r->HintNextDeviceFrame(depth_dev[k + 1], depth_pitch, bgr_dev[k + 1], bgr_pitch);
-            r->StepAsync();
+            r->_defer_apply = k + 1 < count;                   // the next StepAsync is certain to come
+            try { r->StepAsync(); } catch (...) { r->_defer_apply = false; throw; }
         }
+        r->_defer_apply = false;
         r->Sync();                                             // the only host<->device sync of the sequence
         ok = (int)(r->tracked_total - before);
     } else for (int k = 0; k < count; k++) {

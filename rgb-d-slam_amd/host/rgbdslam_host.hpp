@@ -168,7 +168,9 @@ public:
     // fused frame pipeline (include/rgbdslam.h "fused frame pipeline"): the same methods as one
     // launch each, poses taken from the device-resident block, model set A -> B -> A
     void ReseedFused(const rgbdslam_pose_block *pb, int force, OffLineFrame *frame);       // Cpy + InitMask
-    void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *reseed_from);   // Transform..ProjectLabel gather
+    // Transform..ProjectLabel gather; prev_apply != nullptr: the previous frame's deferred apply pass rides on the draw launch
+    void PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *reseed_from,
+                      const UpdateTables *prev_apply = nullptr, const float *prev_history_entry = nullptr);
     void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
     // claim != null: the claim pass of the Graph::Update that follows rides on the merge launch
     // NormalSegmentFused + MergeFused(claim) in three launches (rgbdslam_model_segment_merge_claim); needs planes
@@ -325,6 +327,13 @@ public:
     struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false; } _next_hint;
     // where the hinted next frame is preprocessed: on the merge launch (default) or on the apply launch (RGBDSLAM_NEXT_ON_APPLY=1)
     bool _next_on_merge = getenv("RGBDSLAM_NEXT_ON_APPLY") == nullptr;
+    // The apply pass of Graph::Update may wait for the NEXT frame's draw launch (it reads the model this frame leaves and the
+    // planes; nothing before the next merge writes either): only while a caller that will certainly step the hinted next
+    // frame allows it (run_device_sequence), and any Sync() runs a pending pass first.  RGBDSLAM_APPLY_NOW=1: never.
+    bool _defer_apply = false;
+    bool _defer_apply_enabled = getenv("RGBDSLAM_APPLY_NOW") == nullptr;
+    struct { UpdateTables t; const float *hist = nullptr; bool valid = false; } _deferred;
+    void FlushDeferredApply();
     std::vector<float> _Equations, _Centers;
     DevBuf<float> _Equations_dev;
 private:
