@@ -381,6 +381,20 @@ int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *RGBA, float
                               const uint16_t *Bump, const uint8_t *RGB_bump, const uint8_t *Mask,
                               const float *param_dev, int n, int m, int lvl);
 
+/* DemoStep2's forms of the decode (D2/Primitive.cuh): a cell is empty when mask < 11.
+ * variant 0 = void VertexFromBump(float *VMap_VBO, unsigned short *Bump_dev, unsigned char *RGB_bump_dev,
+ *   unsigned short *Mask_dev, float *param_dev, int n, int m, int lvl) and VertexOnlyFromBump (the same without the unused
+ *   colour argument), D2/Primitive.cu:31-121,704-730: Mask = uint16_t[n*m], output VMap of (n/lvl) x (m/lvl), RGBA / RGB_bump
+ *   unused (may be NULL).
+ * variant 1 = void VertexRGBFromBump(float *VMap_VBO, float *RGB_VBO, unsigned short *Bump_dev, unsigned char *RGB_bump_dev,
+ *   unsigned char *Mask_dev, float *param_dev, int n, int m, int lvl), D2/Primitive.cu:123-179,732-742: Mask = uint8_t[n*m],
+ *   VMap + RGBA (r, g, b, 1) of n x m, cell (i, j) read and written at i*m + j, positioned at (lvl*i, lvl*j).
+ * The reference's kernels test i, j against n, m instead of the output size (a grid rounded up writes past the
+ * sub-sampled output for lvl > 1): the output size is the bound here. */
+int rgbdslam_vertex_from_bump_d2(rgbdslam_ctx *ctx, float *VMap, float *RGBA, const uint16_t *Bump,
+                                 const uint8_t *RGB_bump, const void *Mask, const float *param_dev,
+                                 int n, int m, int lvl, int variant);
+
 /* The same decode for planes [plane_lo, plane_hi) in ONE launch (lvl = 1): the tables are
  * device arrays of per-plane device pointers like Update_cu's; outputs one buffer per plane (the
  * reference keeps one VBO triple per Primitive, Primitive.h:60-66).  For models of hundreds of

@@ -218,6 +218,19 @@ def vertex_from_bump(bump, rgb_bump, mask, param, lvl=1):
     return v, c, mk
 
 
+def vertex_from_bump_d2(bump, rgb_bump, mask, param, lvl=1, variant=0):
+    """DemoStep2's decode (D2/Primitive.cu:31-179): variant 0 -> vertices of the sub-sampled grid (u16 mask),
+    variant 1 -> vertices + RGBA of the full grid (u8 mask)."""
+    n, m = mask.shape
+    no, mo = (n, m) if variant else (n // lvl, m // lvl)
+    v = np.empty((no, mo, 3), np.float32)
+    c = np.empty((no, mo, 4), np.float32)
+    mk = np.ascontiguousarray(mask, np.uint8 if variant else np.uint16)
+    lib().orc_vertex_from_bump_d2(_p(v), _p(c), _p(np.ascontiguousarray(bump, np.uint16)),
+                                  _p(np.ascontiguousarray(rgb_bump, np.uint8)), _p(mk), _p(_f32(param)), n, m, lvl, variant)
+    return (v, c) if variant else v
+
+
 # ---- stage 5 ----------------------------------------------------------------------------------
 def transform_vertex_map(pose, vmap, rgbd):
     n, m, _ = vmap.shape

@@ -861,6 +861,37 @@ void orc_vertex_from_bump(float *VMap, float *RGBA, float *MaskOut, const uint16
         }
 }
 
+/* DemoStep2's decode kernels (D2/Primitive.cu:31-179; variant 0 = VertexFromBump / VertexOnlyFromBump with a 16-bit mask,
+ * variant 1 = VertexRGBFromBump with an 8-bit mask, same-index input and output).  Output size is the bound (see the D1 form). */
+void orc_vertex_from_bump_d2(float *VMap, float *RGBA, const uint16_t *Bump, const uint8_t *RGB_bump, const void *Mask,
+                             const float *param, int n, int m, int lvl, int variant) {
+    int no = variant ? n : n / lvl, mo = variant ? m : m / lvl;
+    for (int i = 0; i < no; i++)
+        for (int j = 0; j < mo; j++) {
+            size_t idx = (size_t)i * mo + j;
+            size_t ref = variant ? idx : (size_t)(lvl * i) * m + (size_t)(lvl * j);
+            unsigned mk = variant ? ((const uint8_t *)Mask)[ref] : ((const uint16_t *)Mask)[ref];
+            if (mk < 11) {                                                       /* D2/Primitive.cu:47,140 */
+                for (int k = 0; k < 3; k++) VMap[3 * idx + k] = 0.0f;
+                if (variant) for (int k = 0; k < 4; k++) RGBA[4 * idx + k] = 0.0f;
+                continue;
+            }
+            float fi = (float)(lvl * i), fj = (float)(lvl * j);                  /* :55-56 */
+            float s0 = (float)((double)(float)Bump[3 * ref] / 60000.0);          /* :59-60 */
+            float s1 = (float)((double)(float)Bump[3 * ref + 1] / 60000.0);
+            float x = (float)((double)(fi + s0) * 2.0 / (double)param[4] + (double)param[6]);   /* :62-63 */
+            float y = (float)((double)(fj + s1) * 2.0 / (double)param[5] + (double)param[7]);
+            float d = (float)((double)param[3] + (((double)(float)Bump[3 * ref + 2] / 2000.0) - 15.0));   /* :65 */
+            VMap[3 * idx] = (x * param[8] + y * param[11]) + d * param[0];       /* :67-69 */
+            VMap[3 * idx + 1] = (x * param[9] + y * param[12]) + d * param[1];
+            VMap[3 * idx + 2] = (x * param[10] + y * param[13]) + d * param[2];
+            if (variant) {                                                       /* :170-173 */
+                for (int k = 0; k < 3; k++) RGBA[4 * idx + k] = (float)((double)(float)RGB_bump[3 * ref + k] / 255.0);
+                RGBA[4 * idx + 3] = 1.0f;
+            }
+        }
+}
+
 /* ===================================================================================== */
 /* Stage 5: prediction                                                                   */
 /* ===================================================================================== */

@@ -187,6 +187,10 @@ class Context:
         _chk(self.lib.rgbdslam_vertex_from_bump(self._h, _ptr(vmap), _ptr(rgba), _ptr(mask_out), _ptr(bump), _ptr(rgb_bump),
                                                 _ptr(mask), _ptr(param), n, m, lvl), "vertex_from_bump")
 
+    def vertex_from_bump_d2(self, vmap, rgba, bump, rgb_bump, mask, param, n, m, lvl, variant):
+        _chk(self.lib.rgbdslam_vertex_from_bump_d2(self._h, _ptr(vmap), _ptr(rgba), _ptr(bump), _ptr(rgb_bump), _ptr(mask), _ptr(param),
+                                                   n, m, lvl, variant), "vertex_from_bump_d2")
+
     def vertex_from_bump_batch(self, vmap_tab, rgba_tab, mask_out_tab, bump_tab, rgb_tab, mask_tab, param_tab, plane_lo, plane_hi, n, m):
         _chk(self.lib.rgbdslam_vertex_from_bump_batch(self._h, _ptr(vmap_tab), _ptr(rgba_tab), _ptr(mask_out_tab), _ptr(bump_tab),
                                                       _ptr(rgb_tab), _ptr(mask_tab), _ptr(param_tab), plane_lo, plane_hi, n, m),

@@ -360,6 +360,40 @@ extern "C" int rgbdslam_vertex_from_bump(rgbdslam_ctx *ctx, float *VMap, float *
     return 0;
 }
 
+// ---- D2/Primitive.cu:31-177: the decode as DemoStep2's viewer calls it ---------------------------------
+// variant 0 = VertexFromBumpKernel / VertexOnlyFromBumpKernel (identical bodies, D2/Primitive.cu:31-121): 16-bit mask (the dump
+// stores mask x 200), vertices only, sub-sampled output grid like D1's.  variant 1 = VertexRGBFromBumpKernel (:123-179): 8-bit
+// mask, vertex + RGBA, input and output indexed by the SAME i * m + j, lvl only scales the cell index in the position.
+// Both: a cell is empty when mask < 11 (no special value 1 as in D1).
+__global__ void k_vertex_from_bump_d2(float *__restrict__ VMap, float *__restrict__ RGBA, const uint16_t *__restrict__ Bump,
+                                      const uint8_t *__restrict__ RGB_bump, const void *__restrict__ Mask,
+                                      const float *__restrict__ param, int n, int m, int lvl, int variant) {
+    const int no = variant ? n : n / lvl, mo = variant ? m : m / lvl;
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= no || j >= mo) return;
+    const size_t idx = (size_t)i * mo + j;
+    const size_t ref = variant ? idx : (size_t)(lvl * i) * m + (size_t)(lvl * j);
+    const unsigned int mk = variant ? (unsigned int)((const uint8_t *)Mask)[ref] : (unsigned int)((const uint16_t *)Mask)[ref];
+    uint8_t cr = 0, cg = 0, cb = 0;
+    if (variant) { cr = RGB_bump[3 * ref]; cg = RGB_bump[3 * ref + 1]; cb = RGB_bump[3 * ref + 2]; }
+    // decode_cell with a mask that passes its own emptiness test; emptiness is decided here
+    BumpCell o = decode_cell(Bump[3 * ref], Bump[3 * ref + 1], Bump[3 * ref + 2], cr, cg, cb, (uint8_t)255, load_param(param),
+                             (float)(lvl * i), (float)(lvl * j), unorm8);
+    if (mk < 11u) { o.v.x = o.v.y = o.v.z = 0.0f; o.c.x = o.c.y = o.c.z = o.c.w = 0.0f; }
+    VMap[3 * idx] = o.v.x; VMap[3 * idx + 1] = o.v.y; VMap[3 * idx + 2] = o.v.z;
+    if (variant) *(float4 *)(RGBA + 4 * idx) = o.c;
+}
+extern "C" int rgbdslam_vertex_from_bump_d2(rgbdslam_ctx *ctx, float *VMap, float *RGBA, const uint16_t *Bump, const uint8_t *RGB_bump,
+                                            const void *Mask, const float *param_dev, int n, int m, int lvl, int variant) {
+    if (!ctx || !VMap || !Bump || !Mask || !param_dev || (variant != 0 && variant != 1)) return RGBDSLAM_E_ARG;
+    if (variant == 1 && (!RGBA || !RGB_bump)) return RGBDSLAM_E_ARG;
+    if (n <= 0 || m <= 0 || lvl <= 0 || n / lvl <= 0 || m / lvl <= 0) return RGBDSLAM_E_ARG;
+    KLAUNCH(ctx, k_vertex_from_bump_d2, variant ? grid2d(n, m) : grid2d(n / lvl, m / lvl), block2d(), VMap, RGBA, Bump, RGB_bump, Mask,
+            param_dev, n, m, lvl, variant);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int rgbdslam_vertex_from_bump_batch(rgbdslam_ctx *ctx, float **VMapTab, float **RGBATab, float **MaskOutTab,
                                                uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab,
                                                int plane_lo, int plane_hi, int n, int m) {

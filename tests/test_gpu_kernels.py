@@ -912,3 +912,36 @@ def test_segment_merge_claim_one_launch(ctx, pkg, orc, pair, synth, shape, nb, d
     grown = (seg_ref > 0).sum() - (lab0 > 0).sum()
     assert grown > 0 and (seg_ref == 0).sum() > 0
     assert (results[1][5] != 0).sum() > 0                      # claims were made
+
+
+@pytest.mark.parametrize("shape,lvl", [((256, 256), 1), ((200, 136), 2), ((67, 130), 3)])
+def test_vertex_from_bump_demostep2_forms(ctx, orc, shape, lvl):
+    """SURVEY 8f N4, the decode as DemoStep2 calls it (D2/Primitive.cu:31-179): 16-bit mask + vertices only on the
+    sub-sampled grid (variant 0), 8-bit mask + vertices and RGBA on the full grid (variant 1); empty = mask < 11."""
+    n, m = shape
+    rng = np.random.default_rng(n + lvl)
+    bump = rng.integers(0, 65536, (n, m, 3)).astype(np.uint16)
+    rgbb = rng.integers(0, 256, (n, m, 3)).astype(np.uint8)
+    param = np.array([0.0, 0.6, 0.8, -1.7, 500.0, 480.0, -0.9, -1.1, 1.0, 0.0, 0.0, 0.0, 0.8, -0.6], np.float32)
+    mask16 = rng.integers(0, 40, (n, m)).astype(np.uint16) * 200 // 7            # values around the threshold and far above 255
+    mask16[::5, ::3] = 10
+    mask16[1::5, ::3] = 11
+    mask16[2::5, ::3] = 1                                                        # D1's special value: empty here
+    no, mo = n // lvl, m // lvl
+    v = torch.full((no, mo, 3), -7.0, device="cuda")
+    ctx.vertex_from_bump_d2(v, None, dev(bump), None, dev(mask16), dev(param), n, m, lvl, 0)
+    want = orc.vertex_from_bump_d2(bump, rgbb, mask16, param, lvl, 0)
+    same(host(v), want)
+    sub = mask16[:no * lvl:lvl, :mo * lvl:lvl]
+    assert ((want == 0).all(axis=2) == (sub < 11)).all() and (sub < 11).any() and (sub >= 11).any()
+    mask8 = np.minimum(mask16, 255).astype(np.uint8)
+    v1 = torch.full((n, m, 3), -7.0, device="cuda")
+    c1 = torch.full((n, m, 4), -7.0, device="cuda")
+    ctx.vertex_from_bump_d2(v1, c1, dev(bump), dev(rgbb), dev(mask8), dev(param), n, m, lvl, 1)
+    wv, wc = orc.vertex_from_bump_d2(bump, rgbb, mask8, param, lvl, 1)
+    same(host(v1), wv)
+    same(host(c1), wc)
+    # where D1's decode (mask >= 11) and DemoStep2's agree on emptiness they give the same vertex
+    d1v, _, _ = orc.vertex_from_bump(bump, rgbb, mask8, param, lvl)
+    keep = mask8[:no * lvl:lvl, :mo * lvl:lvl] >= 11
+    same(want[keep & (sub >= 11)], d1v[keep & (sub >= 11)])

@@ -601,3 +601,31 @@ def test_bump_encode_and_decode_match_float64_formulas(orc, synth):
     # and the decoded points are the fused points to within the quantisation of the code: 1/60000 of a cell in the plane,
     # half of 1/2000 m = 0.25 mm along the normal
     assert np.abs(V[ii, jj] - pt).max() < 2.6e-4
+
+
+def test_demostep2_decode_matches_float64_formula_and_d1():
+    """D2/Primitive.cu:31-179 restated (oracle.vertex_from_bump_d2) against the formula written out in float64 and against
+    the D1 decode on cells both call non-empty."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    n, m, lvl = 48, 40, 2
+    bump = rng.integers(0, 65536, (n, m, 3)).astype(np.uint16)
+    rgbb = rng.integers(0, 256, (n, m, 3)).astype(np.uint8)
+    mask = rng.integers(0, 30, (n, m)).astype(np.uint16)
+    param = np.array([0.0, 0.6, 0.8, -1.7, 500.0, 480.0, -0.9, -1.1, 1.0, 0.0, 0.0, 0.0, 0.8, -0.6], np.float32)
+    v = orc.vertex_from_bump_d2(bump, rgbb, mask, param, lvl, 0)
+    p = param.astype(np.float64)
+    ii, jj = np.meshgrid(np.arange(0, n, lvl)[:n // lvl], np.arange(0, m, lvl)[:m // lvl], indexing="ij")
+    b = bump[ii, jj].astype(np.float64)
+    x = (ii + b[..., 0] / 60000.0) * 2.0 / p[4] + p[6]
+    y = (jj + b[..., 1] / 60000.0) * 2.0 / p[5] + p[7]
+    d = p[3] + (b[..., 2] / 2000.0 - 15.0)
+    ref = np.stack([x * p[8] + y * p[11] + d * p[0], x * p[9] + y * p[12] + d * p[1], x * p[10] + y * p[13] + d * p[2]], axis=-1)
+    ref[mask[ii, jj] < 11] = 0.0
+    assert np.abs(v - ref).max() < 2e-5
+    assert ((v == 0).all(axis=2) == (mask[ii, jj] < 11)).all()
+    v1, c1 = orc.vertex_from_bump_d2(bump, rgbb, np.minimum(mask, 255).astype(np.uint8), param, 1, 1)
+    d1v, d1c, _ = orc.vertex_from_bump(bump, rgbb, mask.astype(np.uint8), param, 1)
+    keep = mask >= 11
+    assert np.array_equal(v1[keep], d1v[keep]) and np.array_equal(c1[keep], d1c[keep])
+    assert (c1[~keep] == 0).all() and (v1[~keep] == 0).all()
