@@ -381,7 +381,11 @@ __device__ __forceinline__ void seg3_stage(const SegArgs &a, const SegTileRegs &
 }
 // after seg3_stage.  Returns the label of the thread's own pixel after the third pass.
 __device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, const int j0, const int tid, SegTileLds &S) {
+#ifdef SEG3_NOQUEUE                                  // (timing experiments only: the passes never run)
+    const int nq = 0;
+#else
     const int nq = (int)S.qn;                        // uniform
+#endif
     uint8_t *const L = &S.lab[0][0];
     if (nq > 0) {
         const float *__restrict__ V = a.VMap;

@@ -945,3 +945,90 @@ def test_vertex_from_bump_demostep2_forms(ctx, orc, shape, lvl):
     d1v, _, _ = orc.vertex_from_bump(bump, rgbb, mask8, param, lvl)
     keep = mask8[:no * lvl:lvl, :mo * lvl:lvl] >= 11
     same(want[keep & (sub >= 11)], d1v[keep & (sub >= 11)])
+
+
+@pytest.mark.parametrize("tracked", [1, 0])
+def test_rider_entry_points_equal_separate_calls(ctx, pkg, orc, pair, synth, tracked):
+    """The two entry points that let an independent job ride on a frame launch, against the same jobs as separate calls,
+    bit for bit: rgbdslam_model_segment_merge_claim_preprocess (next frame's LoadFrame on the merge launch) and
+    rgbdslam_model_predict_apply (previous frame's apply pass on the z-buffer launch, posed by its history entry) --
+    for a tracked block and for a lost one (the predict then re-seeds the model and nothing else of the frame runs; the
+    riders do not look at this frame's block)."""
+    import ctypes as C
+    n, m, nb, N_prim = 480, 640, 3, 256
+    lib = ctx.lib
+    ctx.set_calibration_matrix(synth.TUM_CALIB)
+    rng = np.random.default_rng(11 + tracked)
+    eq, _ = synth.plane_equations()
+    Pg = pose16(synth.euler_xyz(0.003, -0.002, 0.001), np.array([0.001, -0.002, 0.002]))
+    Prel = pose16(synth.euler_xyz(0.002, 0.001, -0.001), np.array([0.003, 0.001, -0.002]))
+    Prel_inv = np.linalg.inv(Prel.reshape(4, 4).T).T.reshape(-1).astype(np.float32)
+    v0, nrm0 = pair["v0"], pair["n0"]
+    lab0 = orc.seed_labels(v0, nrm0, Pg, eq)
+    lab0[rng.random((n, m)) < 0.05] = 0
+    mask0 = rng.integers(9, 60, (n, m)).astype(np.uint8)
+    params = _plane_setup(synth, N_prim)[1]
+    pb_h = np.zeros(76, np.float32)
+    pb_h[24:28] = np.array([tracked, 5, 0, 1], np.int32).view(np.float32)
+    pb_h[28:44], pb_h[44:60], pb_h[60:76] = Prel, Prel_inv, Pg
+    hist_h = np.zeros(16, np.float32)                           # the PREVIOUS frame's entry: poseR (col-major 3x3), poset, tracked
+    hist_h[:9] = Pg.reshape(4, 4)[:3, :3].reshape(-1)
+    hist_h[9:12] = Pg[12:15]
+    hist_h[12] = 1.0
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    f = C.c_float
+    g_eq = dev(eq)
+    g_p = [dev(x) for x in params]
+    g_d0, g_d1, g_c1 = dev(pair["d0"]), dev(pair["d1"]), dev(pair["c1"])
+    g_fv, g_fn, g_frgb = dev(pair["v1"]), dev(pair["n1"]), dev(pair["rgb1"])
+    out = []
+    for riders in (False, True):
+        pb = dev(pb_h); hist = dev(hist_h)
+        V, R, M, L = dev(v0), dev(pair["rgbd0"]), dev(mask0), dev(lab0)       # model set "in" (re-seeded when lost)
+        Nin = dev(nrm0)
+        Va, Ra = torch.zeros(n, m, 3, device="cuda"), torch.zeros(n, m, 4, device="cuda")
+        Ma, La = torch.zeros(n, m, dtype=torch.uint8, device="cuda"), torch.zeros(n, m, dtype=torch.uint8, device="cuda")
+        zbuf = torch.full((n, m), -1, dtype=torch.int64, device="cuda")
+        g_b = [torch.zeros(N_prim, N_prim, 3, dtype=torch.int16, device="cuda") for _ in range(nb)]
+        g_c = [torch.zeros(N_prim, N_prim, 3, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        g_m = [torch.full((N_prim, N_prim), 10, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        g_k = [torch.zeros(N_prim, N_prim, dtype=torch.int64, device="cuda") for _ in range(nb)]
+        t_b, t_c, t_m, t_p, t_k = (_ptr_table(x) for x in (g_b, g_c, g_m, g_p, g_k))
+        # the previous frame's claim pass (stamp 3) on the model it left
+        assert lib.rgbdslam_model_merge_claim(ctx._h, P(dev(np.concatenate([pb_h[:24], np.array([1, 5, 0, 1], np.int32).view(np.float32), pb_h[28:]]))),
+                                              P(R), P(M), P(g_d0), C.c_size_t(2 * m), P(dev(pair["rgb0"])), P(Ra), P(Ma), P(Va),
+                                              P(torch.zeros(n, m, 3, device="cuda")), P(L), P(t_m), P(t_p), P(t_k), C.c_uint32(3), N_prim,
+                                              N_prim, n, m, 0, nb) == 0
+        R.copy_(Ra); M.copy_(Ma); V.copy_(Va)                                  # = the merged model of the previous frame
+        pred = (P(pb), P(V), P(R), P(M), P(L), P(zbuf), P(Va), P(Ra), P(Ma), P(La), f(0.1), f(0.5), f(10.0), n, m, P(g_fv), P(g_fn),
+                P(g_frgb), P(g_d1), C.c_size_t(2 * m), P(Nin))
+        apply_tabs = (P(t_b), P(t_c), P(t_m), P(t_p), P(t_k), C.c_uint32(3))
+        if riders:
+            assert lib.rgbdslam_model_predict_apply(ctx._h, *pred, P(hist), *apply_tabs, N_prim, N_prim, 0, nb) == 0
+        else:
+            assert lib.rgbdslam_update_apply_from_history(ctx._h, P(hist), *apply_tabs, P(V), P(R), P(M), P(L), N_prim, N_prim, n, m, 0, nb) == 0
+            assert lib.rgbdslam_model_predict(ctx._h, *pred) == 0
+        # this frame: growth passes + merge + claim (stamp 4) (+ the next frame's preprocessing)
+        nseg = torch.zeros(n, m, 3, device="cuda")
+        fV, fN, fRGB = (torch.full((n, m, 3), -3.0, device="cuda") for _ in range(3))
+        gx, gy = torch.full((n, m), -3.0, device="cuda"), torch.full((n, m), -3.0, device="cuda")
+        smc = (P(pb), P(nseg), P(Va), P(La), P(L), P(g_eq), nb, f(0.1), f(0.9), P(Ra), P(Ma), P(g_d1), C.c_size_t(2 * m), P(g_frgb),
+               P(R), P(M), P(V), P(Nin), P(t_m), P(t_p), P(t_k), C.c_uint32(4), N_prim, N_prim, n, m, 0, nb)
+        nxt = (P(g_d1), C.c_size_t(2 * m), P(g_c1), C.c_size_t(3 * m), P(fV), P(fN), P(fRGB), P(gx), C.c_size_t(4 * m), P(gy), C.c_size_t(4 * m))
+        if riders:
+            assert lib.rgbdslam_model_segment_merge_claim_preprocess(ctx._h, *smc, *nxt) == 0
+        else:
+            assert lib.rgbdslam_model_segment_merge_claim(ctx._h, *smc) == 0
+            assert lib.rgbdslam_frame_preprocess(ctx._h, *nxt, n, m) == 0
+        ctx.synchronize()
+        out.append([host(x) for x in (V, R, M, L, Nin, Va, Ra, Ma, La, fV, fN, fRGB, gx, gy, zbuf)] +
+                   [np.stack([host(x) for x in tab]) for tab in (g_b, g_c, g_m, g_k)])
+    for a, b in zip(out[1], out[0]):
+        same(a, b)
+    bumps, cellmasks = out[1][15], out[1][17]
+    assert (cellmasks > 10).sum() > 1000 and (bumps != 0).sum() > 1000        # the deferred apply pass wrote cells
+    same(out[1][9], pair["v1"])                                                # the next frame's maps are the oracle's
+    same(out[1][10], pair["n1"])
+    if not tracked:
+        same(out[1][0], pair["v1"])                                            # lost: model := input frame
+        assert (out[1][14] == -1).all()
