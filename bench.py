@@ -45,8 +45,8 @@ def algo_bytes(kernel, n, m, level_iters):
 
 # per pixel, fused frame kernels: inputs read once + outputs written once
 PER_PX = {"k_frame_preprocess": 2 + 3 + 12 + 12 + 12 + 4 + 4,          # depth u16, BGR8 -> VMap, NMap, RGB, Gx, Gy
-          "k_predict_draw": 12,                                        # VMap in (z-buffer atomics not counted)
-          "k_predict_resolve": 8 + 12 + 16 + 1 + 1 + 12 + 16 + 1 + 1,  # zbuf, VMap/RGBD/Mask/Label in -> out
+          "k_predict_draw": 12 + 20,                                   # VMap in -> projected vertices out (z-buffer atomics not counted)
+          "k_predict_resolve<true>": 8 + 20 + 16 + 1 + 1 + 12 + 16 + 1 + 1,   # zbuf, projected vertices, RGBD/Mask/Label in -> out
           "k_normal_segment": 12 + 12 + 1 + 1,                         # VMap -> NMap, Label in/out
           "k_segment_pass_pb": 12 + 12 + 1 + 1,
           "k_model_merge": 16 + 1 + 2 + 12 + 16 + 1 + 12 + 12 + 1 + 1 + 8,   # RGBD, Mask, depth, RGB in -> RGBD, Mask, VMap, NMap; + claim pass: Label, cell mask, claim word
@@ -156,7 +156,7 @@ def hbm_bound_kernels(pkg, lib, synth, torch, device):
     def run_single():                                # frame by frame: no next-frame hint, so the stand-alone kernels run
         for i in order:
             rg.run_device_sequence([dd[i]], [bb[i]])
-    for kernel, run in (("k_segment3_merge_claim", run_seq), ("k_predict_resolve", run_seq), ("k_predict_draw", run_seq),
+    for kernel, run in (("k_segment3_merge_claim", run_seq), ("k_predict_resolve<true>", run_seq), ("k_predict_draw", run_seq),
                         ("k_frame_preprocess", run_single), ("k_update<true>", run_single)):
         tot, cnt = measure(ch, kernel, run)
         if cnt == 0:

@@ -236,7 +236,13 @@ int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bl
                             * performs rgbdslam_model_reseed on set "in" (VMap_in, NMap_reseed, RGBD_in,
                             * Mask_in are then written) -- GP-demo.cpp:189-193 without an extra launch */
                            const float *frame_VMap, const float *frame_NMap, const float *frame_RGB,
-                           const uint16_t *depth, size_t depth_pitch_bytes, float *NMap_reseed);
+                           const uint16_t *depth, size_t depth_pitch_bytes, float *NMap_reseed,
+                           /* optional scratch, RGBDSLAM_PREDICT_SCRATCH_BYTES(n, m) bytes, 16-byte aligned (contents
+                            * need not survive the call): the z-buffer pass leaves every vertex's projection there and
+                            * the resolve shades from it instead of projecting the winner's vertices again; NULL: it
+                            * recomputes them.  Same bits either way. */
+                           void *vertex_scratch);
+#define RGBDSLAM_PREDICT_SCRATCH_BYTES(n, m) ((size_t)20 * (size_t)(n) * (size_t)(m))
 /* The same, with the APPLY pass of the PREVIOUS frame's Graph::Update riding on the draw launch (a caller that enqueues a
  * recorded sequence may defer that pass by one frame: it reads the model the previous frame left -- VMap_in, RGBD_in, Mask_in,
  * Label_in -- and is posed and gated by that frame's immutable history entry, rgbdslam_track_frame's history row). */
@@ -246,7 +252,7 @@ int rgbdslam_model_predict_apply(rgbdslam_ctx *ctx, const rgbdslam_pose_block *p
                                  uint8_t *Mask_out, uint8_t *Label_out, float thresh, float znear, float zfar,
                                  int n, int m, const float *frame_VMap, const float *frame_NMap,
                                  const float *frame_RGB, const uint16_t *depth, size_t depth_pitch_bytes,
-                                 float *NMap_reseed, const float *prev_history_entry_dev, uint16_t **BumpTab,
+                                 float *NMap_reseed, void *vertex_scratch, const float *prev_history_entry_dev, uint16_t **BumpTab,
                                  uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
                                  uint32_t prev_stamp, int N_prim, int M_prim, int plane_lo, int plane_hi);
 /* The apply pass alone, posed and gated by a history entry (what a deferred apply pass becomes when no next frame comes). */

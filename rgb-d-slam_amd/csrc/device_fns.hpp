@@ -262,10 +262,12 @@ __device__ __forceinline__ void ras_draw(unsigned long long *__restrict__ zbuf, 
     if (!ras_setup(vtx, c, T)) return;
     ras_draw_tri(zbuf, T, tri_id, znear, zfar, n, m);
 }
-// resolve pass for the pixel (px, py) covered by triangle vtx with attributes att (r, g, b, depth/100)
-__device__ __forceinline__ float4 ras_shade(const F3 *vtx, const float4 *att, const CalibV &c, int px, int py) {
+// resolve pass for the pixel (px, py) covered by the triangle of the three PROJECTED vertices with attributes att
+// (r, g, b, depth/100)
+__device__ __forceinline__ float4 ras_shade_projected(const RasVert &pa, const RasVert &pb, const RasVert &pd, const float4 *att,
+                                                      int px, int py) {
     RasTri T; long long w[3];
-    ras_setup(vtx, c, T);
+    ras_setup_projected(pa, pb, pd, T);
     ras_cover(T, px, py, w);
     double b0 = (double)w[0] * T.inv_d[0], b1 = (double)w[1] * T.inv_d[1], b2 = (double)w[2] * T.inv_d[2];
     double W = (b0 + b1) + b2;
@@ -277,6 +279,9 @@ __device__ __forceinline__ float4 ras_shade(const F3 *vtx, const float4 *att, co
     o.z = (float)(((b0 * (double)A0.z + b1 * (double)A1.z) + b2 * (double)A2.z) / W);
     o.w = (float)(((b0 * (double)A0.w + b1 * (double)A1.w) + b2 * (double)A2.w) / W);
     return o;
+}
+__device__ __forceinline__ float4 ras_shade(const F3 *vtx, const float4 *att, const CalibV &c, int px, int py) {
+    return ras_shade_projected(ras_project(vtx[0], c), ras_project(vtx[1], c), ras_project(vtx[2], c), att, px, py);
 }
 __device__ __forceinline__ void quad_vertex_ids(uint32_t q, const uint32_t *__restrict__ index, int m, uint32_t *id) {
     if (index) {

@@ -71,6 +71,12 @@ __device__ __forceinline__ F3 warp_vertex(const float *P, F3 v) {      // select
 #define PD_ROWS (TILE_H + 1)
 #define PD_COLS (TILE_W + 1)
 struct PdVert { F3 v; RasVert p; };
+// What the draw leaves per vertex for the resolve when the caller gives the room (vertex_scratch: 16 + 4 bytes per pixel):
+// the projection (1/256-pixel position, reciprocal depth) and the warped depth.  The resolve then shades the winning
+// triangle from three of these records instead of warping and projecting its vertices a second time (two f32 divisions and
+// one f64 reciprocal each: 207 of its 578 instructions).
+struct ProjVert { int X, Y; double inv_d; };
+static_assert(sizeof(ProjVert) == 16, "ProjVert");
 __device__ __forceinline__ PdVert pd_vertex(const float *P, const CalibV &c, F3 v, bool exists) {
     PdVert o;
     o.v = warp_vertex(P, v);
@@ -81,7 +87,7 @@ __device__ __forceinline__ PdVert pd_vertex(const float *P, const CalibV &c, F3 
 __global__ __launch_bounds__(TILE_W * TILE_H)
 void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
                     unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
-                    UpdateArgs upd, int rows_draw, int n, int m) {
+                    UpdateArgs upd, int rows_draw, ProjVert *__restrict__ pv, float *__restrict__ zw, int n, int m) {
     // Tile rows from rows_draw on (if the grid has them): the APPLY pass of the PREVIOUS frame's Graph::Update, deferred by
     // the caller (posed by that frame's history entry).  It reads what this launch reads -- the model the previous frame
     // left -- and the planes; nothing in this launch writes either.
@@ -109,6 +115,11 @@ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__r
     if (!tracked) return;                             // (the resolve launch re-seeds the model)
     {
         const PdVert a = pd_vertex(P, c, v1, ex1);
+        if (pv && ex1) {                              // every vertex of the image has exactly one owner
+            ProjVert o; o.X = a.p.X; o.Y = a.p.Y; o.inv_d = a.p.inv_d;
+            pv[(size_t)i * m + j] = o;
+            zw[(size_t)i * m + j] = a.v.z;
+        }
         s_v[0][threadIdx.y][threadIdx.x] = a.v.x; s_v[1][threadIdx.y][threadIdx.x] = a.v.y; s_v[2][threadIdx.y][threadIdx.x] = a.v.z;
         s_xy[0][threadIdx.y][threadIdx.x] = a.p.X; s_xy[1][threadIdx.y][threadIdx.x] = a.p.Y;
         s_inv[threadIdx.y][threadIdx.x] = a.p.inv_d; s_ok[threadIdx.y][threadIdx.x] = a.p.ok ? 1 : 0;
@@ -121,7 +132,9 @@ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__r
     }
     __syncthreads();
     if (i > n - 2 || j > m - 2) return;               // no quad here
-    const uint32_t q = (uint32_t)(i * (m - 1) + j);
+    // triangle ids count in PIXEL indices (2 * (i * m + j) + t, not the quad index i * (m - 1) + j): the same order, so the
+    // same winner on ties, and the resolve gets the quad's first vertex with a shift instead of a division by m - 1
+    const uint32_t q = (uint32_t)(i * m + j);
     // corners in the order of quad_vertex_ids: (i, j) (i, j+1) (i+1, j+1) (i+1, j)
     const int rr[4] = {(int)threadIdx.y, (int)threadIdx.y, (int)threadIdx.y + 1, (int)threadIdx.y + 1};
     const int cc[4] = {(int)threadIdx.x, (int)threadIdx.x + 1, (int)threadIdx.x + 1, (int)threadIdx.x};
@@ -143,11 +156,13 @@ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__r
 // ---- resolve + PredictedFrame::ReadFrame + ProjectMask + the gather of ProjectLabel -------------------
 // (Frame.cpp:229-245,372-393).  Reads model set "in", writes model set "out" (ping-pong): the texel
 // never reaches memory.  Also resets the z-buffer word.
+template <bool PROJ>
 __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap_in,
                                   const float *__restrict__ RGBD_in, const uint8_t *__restrict__ Mask_in,
                                   const uint8_t *__restrict__ Label_in, unsigned long long *__restrict__ zbuf,
                                   float *__restrict__ VMap_out, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
-                                  uint8_t *__restrict__ Label_out, CalibV c, ReseedArgs rs, int n, int m) {
+                                  uint8_t *__restrict__ Label_out, CalibV c, ReseedArgs rs, const ProjVert *__restrict__ pv,
+                                  const float *__restrict__ zw, int n, int m) {
     const bool tracked = pb_tracked(pb);               // round trip shared with the z-buffer word (see k_predict_draw)
     int px = blockIdx.x * TILE_W + threadIdx.x, py = blockIdx.y * TILE_H + threadIdx.y;
     if (py >= n || px >= m) return;
@@ -164,24 +179,49 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
     if (key != ZBUF_EMPTY) {
         zbuf[p] = ZBUF_EMPTY;
         const float *P = pb->P_rel;
-        uint32_t tri_id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), id[4], vid[3];
-        quad_vertex_ids(tri_id >> 1, nullptr, m, id);
-        if (tri_id & 1) { vid[0] = id[0]; vid[1] = id[2]; vid[2] = id[3]; } else { vid[0] = id[0]; vid[1] = id[1]; vid[2] = id[2]; }
-        F3 vtx[3];
+        const uint32_t tri_id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), v0 = tri_id >> 1;   // see k_predict_draw
+        uint32_t vid[3];
+        vid[0] = v0;
+        if (tri_id & 1) { vid[1] = v0 + (uint32_t)m + 1u; vid[2] = v0 + (uint32_t)m; } else { vid[1] = v0 + 1u; vid[2] = v0 + (uint32_t)m + 1u; }
         float4 att[3];
+        if (PROJ) {
+            int4 pr[3];
+            float z[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            vtx[k] = ld3(VMap_in, vid[k]);
-            att[k] = *(const float4 *)(RGBD_in + 4 * (size_t)vid[k]);
+            for (int k = 0; k < 3; k++) {
+                pr[k] = *(const int4 *)(pv + vid[k]);
+                z[k] = zw[vid[k]];
+                att[k] = *(const float4 *)(RGBD_in + 4 * (size_t)vid[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                          // nine loads in flight
+                asm volatile("" : "+v"(pr[k].x), "+v"(pr[k].y), "+v"(pr[k].z), "+v"(pr[k].w), "+v"(z[k]));
+                pin_loaded(att[k]);
+            }
+            RasVert q[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                q[k].X = pr[k].x; q[k].Y = pr[k].y; q[k].ok = true;
+                q[k].inv_d = __hiloint2double(pr[k].w, pr[k].z);
+                att[k].w = depth_attr(z[k]);                       // Kernel.cu:368-371
+            }
+            tex = ras_shade_projected(q[0], q[1], q[2], att, px, py);
+        } else {
+            F3 vtx[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                vtx[k] = ld3(VMap_in, vid[k]);
+                att[k] = *(const float4 *)(RGBD_in + 4 * (size_t)vid[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { pin_loaded(vtx[k]); pin_loaded(att[k]); }   // six loads in flight, then the warps
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                vtx[k] = warp_vertex(P, vtx[k]);
+                att[k].w = depth_attr(vtx[k].z);                   // Kernel.cu:368-371
+            }
+            tex = ras_shade(vtx, att, c, px, py);
         }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { pin_loaded(vtx[k]); pin_loaded(att[k]); }   // six loads in flight, then the warps
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            vtx[k] = warp_vertex(P, vtx[k]);
-            att[k].w = depth_attr(vtx[k].z);                       // Kernel.cu:368-371
-        }
-        tex = ras_shade(vtx, att, c, px, py);
     }
     F3 v; v.x = v.y = v.z = 0.0f;
     float4 o; o.x = o.y = o.z = o.w = 0.0f;
@@ -626,7 +666,7 @@ static int model_predict_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose
                               float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
                               float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
                               const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
-                              const UpdateArgs *apply) {
+                              void *vertex_scratch, const UpdateArgs *apply) {
     if (!ctx || !pose_block_dev || !VMap_in || !RGBD_in || !Mask_in || !Label_in || !zbuf || !VMap_out || !RGBD_out ||
         !Mask_out || !Label_out)
         return RGBDSLAM_E_ARG;
@@ -642,10 +682,19 @@ static int model_predict_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose
     const int rows_draw = (int)gd.y;
     UpdateArgs upd = {};
     if (apply) { upd = *apply; gd.y *= 2; }
+    if (vertex_scratch && ((uintptr_t)vertex_scratch & 15)) return RGBDSLAM_E_ARG;
+    ProjVert *pv = (ProjVert *)vertex_scratch;
+    float *zw = pv ? (float *)(pv + (size_t)n * m) : nullptr;
     KLAUNCH(ctx, k_predict_draw, gd, block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
-            ctx->calib, znear, zfar, upd, rows_draw, n, m);
-    KLAUNCH(ctx, k_predict_resolve, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
-            (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs, n, m);
+            ctx->calib, znear, zfar, upd, rows_draw, pv, zw, n, m);
+    if (pv)
+        KLAUNCH(ctx, k_predict_resolve<true>, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
+                (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs, (const ProjVert *)pv,
+                (const float *)zw, n, m);
+    else
+        KLAUNCH(ctx, k_predict_resolve<false>, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
+                (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs, (const ProjVert *)nullptr,
+                (const float *)nullptr, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -653,9 +702,11 @@ extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_blo
                                       const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
                                       float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
                                       float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
-                                      const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed) {
+                                      const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
+                                      void *vertex_scratch) {
     return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in, zbuf, VMap_out, RGBD_out, Mask_out, Label_out,
-                              thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed, nullptr);
+                              thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed,
+                              vertex_scratch, nullptr);
 }
 // The same + the APPLY pass of the PREVIOUS frame's Graph::Update (rgbdslam_update_apply_from_history on VMap_in, RGBD_in,
 // Mask_in, Label_in -- the model that frame left), riding on the draw launch.
@@ -664,7 +715,7 @@ extern "C" int rgbdslam_model_predict_apply(rgbdslam_ctx *ctx, const rgbdslam_po
                                             float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
                                             float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
                                             const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
-                                            const float *prev_history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
+                                            void *vertex_scratch, const float *prev_history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
                                             uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t prev_stamp,
                                             int N_prim, int M_prim, int plane_lo, int plane_hi) {
     if (!prev_history_entry_dev || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab) return RGBDSLAM_E_ARG;
@@ -675,7 +726,8 @@ extern "C" int rgbdslam_model_predict_apply(rgbdslam_ctx *ctx, const rgbdslam_po
     UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, prev_stamp, VMap_in, RGBD_in, Mask_in, Label_in,
                     nullptr, P, nullptr, prev_history_entry_dev, N_prim, M_prim, n, m, plane_lo, plane_hi};
     return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in, zbuf, VMap_out, RGBD_out, Mask_out, Label_out,
-                              thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed, &a);
+                              thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed,
+                              vertex_scratch, &a);
 }
 
 extern "C" int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap,

@@ -388,13 +388,15 @@ void PredictedFrame::ReseedFused(const rgbdslam_pose_block *pb, int force, OffLi
 }
 void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, float zfar, OffLineFrame *frame,
                                   const UpdateTables *prev_apply, const float *prev_history_entry) {
+    if (!_vertex_scratch.p && !getenv("RGBDSLAM_NO_VERTEX_SCRATCH"))      // projections handed from the draw to the resolve
+        _vertex_scratch.alloc((RGBDSLAM_PREDICT_SCRATCH_BYTES(_n, _m) + 3) / 4, false);
     // frame != null: a lost frame re-seeds the model inside the same launch (Cpy + InitMask, GP-demo.cpp:190-191)
     if (prev_apply) {
         check(rgbdslam_model_predict_apply(_ctx, pb, _VMap_dev.p, _RGB_dev.p, _Mask_dev, _Label_dev, _zbuf.p, _VMap_alt.p, _RGB_alt.p,
                                            _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m, frame ? frame->getVMap() : nullptr,
                                            frame ? frame->getNMap() : nullptr, frame ? frame->getRGB() : nullptr,
                                            frame ? frame->depth() : nullptr, frame ? frame->depth_pitch() : 0, _NMap_dev.p,
-                                           prev_history_entry, prev_apply->Bump, prev_apply->RGB, prev_apply->Mask, prev_apply->Param,
+                                           _vertex_scratch.p, prev_history_entry, prev_apply->Bump, prev_apply->RGB, prev_apply->Mask, prev_apply->Param,
                                            prev_apply->Claim, prev_apply->stamp, prev_apply->N_prim, prev_apply->M_prim,
                                            prev_apply->plane_lo, prev_apply->plane_hi), "model_predict + previous Update_cu (apply)");
         return;
@@ -402,7 +404,8 @@ void PredictedFrame::PredictFused(const rgbdslam_pose_block *pb, float znear, fl
     check(rgbdslam_model_predict(_ctx, pb, _VMap_dev.p, _RGB_dev.p, _Mask_dev, _Label_dev, _zbuf.p, _VMap_alt.p, _RGB_alt.p,
                                  _Mask_dev_swap, _Label_dev_swap, 0.1f, znear, zfar, _n, _m, frame ? frame->getVMap() : nullptr,
                                  frame ? frame->getNMap() : nullptr, frame ? frame->getRGB() : nullptr,
-                                 frame ? frame->depth() : nullptr, frame ? frame->depth_pitch() : 0, _NMap_dev.p), "model_predict");
+                                 frame ? frame->depth() : nullptr, frame ? frame->depth_pitch() : 0, _NMap_dev.p, _vertex_scratch.p),
+          "model_predict");
 }
 void PredictedFrame::NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans) {
     // projected labels are in _Label_dev_swap; an odd number of passes brings them back to _Label_dev

@@ -193,6 +193,7 @@ private:
     DevBuf<uint8_t> _mask_a, _mask_b, _label_a, _label_b;
     DevBuf<uint32_t> _Index_dev;
     DevBuf<uint64_t> _zbuf;
+    DevBuf<float> _vertex_scratch;       // rgbdslam_model_predict's optional scratch (RGBDSLAM_PREDICT_SCRATCH_BYTES)
 };
 
 // ---- D1/Primitive.h:17-237 (data model of one Bump image) ---------------------------------------

@@ -989,6 +989,7 @@ def test_rider_entry_points_equal_separate_calls(ctx, pkg, orc, pair, synth, tra
         Va, Ra = torch.zeros(n, m, 3, device="cuda"), torch.zeros(n, m, 4, device="cuda")
         Ma, La = torch.zeros(n, m, dtype=torch.uint8, device="cuda"), torch.zeros(n, m, dtype=torch.uint8, device="cuda")
         zbuf = torch.full((n, m), -1, dtype=torch.int64, device="cuda")
+        vs = torch.zeros(5 * n * m, dtype=torch.float32, device="cuda")          # RGBDSLAM_PREDICT_SCRATCH_BYTES
         g_b = [torch.zeros(N_prim, N_prim, 3, dtype=torch.int16, device="cuda") for _ in range(nb)]
         g_c = [torch.zeros(N_prim, N_prim, 3, dtype=torch.uint8, device="cuda") for _ in range(nb)]
         g_m = [torch.full((N_prim, N_prim), 10, dtype=torch.uint8, device="cuda") for _ in range(nb)]
@@ -1001,7 +1002,7 @@ def test_rider_entry_points_equal_separate_calls(ctx, pkg, orc, pair, synth, tra
                                               N_prim, n, m, 0, nb) == 0
         R.copy_(Ra); M.copy_(Ma); V.copy_(Va)                                  # = the merged model of the previous frame
         pred = (P(pb), P(V), P(R), P(M), P(L), P(zbuf), P(Va), P(Ra), P(Ma), P(La), f(0.1), f(0.5), f(10.0), n, m, P(g_fv), P(g_fn),
-                P(g_frgb), P(g_d1), C.c_size_t(2 * m), P(Nin))
+                P(g_frgb), P(g_d1), C.c_size_t(2 * m), P(Nin), P(vs) if riders else P(None))   # the scratch form must give the same bits
         apply_tabs = (P(t_b), P(t_c), P(t_m), P(t_p), P(t_k), C.c_uint32(3))
         if riders:
             assert lib.rgbdslam_model_predict_apply(ctx._h, *pred, P(hist), *apply_tabs, N_prim, N_prim, 0, nb) == 0
