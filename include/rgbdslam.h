@@ -272,12 +272,14 @@ int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_bloc
                          const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
                          size_t depth_pitch_bytes, const float *RGB, float *RGBD_out,
                          uint8_t *Mask_out, float *VMap_out, float *NMap_out, int n, int m);
-/* rgbdslam_model_normal_segment followed by rgbdslam_model_merge_claim, as three launches instead of four:
- * [first label-growth pass + Merge] -> [second pass] -> [third pass + claim pass of Graph::Update].  Merge reads no labels
- * and the growth passes read nothing Merge writes once they have a normal map of their own (NMap_seg != NMap_out), so
- * the two share a launch (GP-demo.cpp:232-249,260; Frame.cpp:242,300-333,395; RG.cu:906-912).  Needs nbPlans > 0.
- * NMap_seg is scratch of the growth passes: on return it holds the predicted frame's normal only where a pixel had no label
- * before the first pass (the only place a pass reads it); the model's normals are NMap_out. */
+/* rgbdslam_model_normal_segment followed by rgbdslam_model_merge_claim, as ONE launch instead of four: Merge reads no
+ * labels and the label growth reads nothing Merge writes, so the two are independent kinds of tile of one grid; the three
+ * growth passes of a tile run out of LDS on the tile + 3 rings of labels, and the claim pass of Graph::Update follows in the
+ * same tile (GP-demo.cpp:232-249,260; Frame.cpp:242,300-333,395; RG.cu:906-912).  Same labels
+ * (left in Label_swap, as after three passes), same model maps, same claim words as the operator sequence.  Needs
+ * nbPlans > 0.  Label's contents after the call are unspecified (the operator sequence leaves the second pass there).
+ * NMap_seg is scratch (3 * n * m floats, != NMap_out) that only the three-launch form of the same work touches
+ * (RGBDSLAM_SEG3=0, kept for A/B measurements); the model's normals are NMap_out. */
 int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
                                        const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap, const float *Equations_dev,
                                        int nbPlans, float epsilon, float alpha, const float *RGBD_in, const uint8_t *Mask_in,

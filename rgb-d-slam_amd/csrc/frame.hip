@@ -781,9 +781,10 @@ extern "C" int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose
     return 0;
 }
 
-// rgbdslam_model_normal_segment + rgbdslam_model_merge_claim as THREE launches instead of four: [first growth pass +
-// merge] -> [second pass] -> [third pass + claim].  NMap_seg = the normal map of the predicted frame that the growth
-// passes use; it must not be the merge's NMap_out.  Needs planes (nbPlans > 0).
+// rgbdslam_model_normal_segment + rgbdslam_model_merge_claim as ONE launch (k_segment3_merge_claim), or, with
+// RGBDSLAM_SEG3=0, as the three launches this replaced: [first growth pass + merge] -> [second pass] -> [third pass +
+// claim], where NMap_seg = the normal map of the predicted frame that the growth passes use (not the merge's NMap_out).
+// Needs planes (nbPlans > 0).  next != nullptr: the next input frame's preprocessing rides along.
 static int segment_merge_claim_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
                                     const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap,
                                     const float *Equations_dev, int nbPlans, float epsilon, float alpha,

@@ -173,7 +173,7 @@ public:
                       const UpdateTables *prev_apply = nullptr, const float *prev_history_entry = nullptr);
     void NormalSegmentFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans);
     // claim != null: the claim pass of the Graph::Update that follows rides on the merge launch
-    // NormalSegmentFused + MergeFused(claim) in three launches (rgbdslam_model_segment_merge_claim); needs planes
+    // NormalSegmentFused + MergeFused(claim) in one launch (rgbdslam_model_segment_merge_claim); needs planes
     // next_depth != nullptr: the preprocessing of that next device frame rides on the launch (into frame's other buffer set)
     void SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float *Equations_dev, int nbPlans, OffLineFrame *frame, const UpdateTables &claim,
                                 const uint16_t *next_depth = nullptr, size_t next_depth_pitch = 0, const uint8_t *next_bgr = nullptr,
@@ -189,7 +189,7 @@ private:
     rgbdslam_ctx *_ctx;
     DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev, _tex;
     DevBuf<float> _VMap_alt, _RGB_alt;   // model set B of the fused pipeline
-    DevBuf<float> _NMap_seg;             // normals of the predicted frame for the label growth (SegmentMergeClaimFused)
+    DevBuf<float> _NMap_seg;             // scratch of SegmentMergeClaimFused's three-launch form (RGBDSLAM_SEG3=0)
     DevBuf<uint8_t> _mask_a, _mask_b, _label_a, _label_b;
     DevBuf<uint32_t> _Index_dev;
     DevBuf<uint64_t> _zbuf;
