@@ -153,10 +153,6 @@ int rgbdslam_icp_loop_faults(rgbdslam_ctx *ctx, int *faults);
  * assumption (+ ~0.5 us per Gauss-Newton iteration).  rgbdslam_icp_line_rejections: count since the last call; synchronises. */
 int rgbdslam_set_icp_line_check(rgbdslam_ctx *ctx, int on);
 int rgbdslam_icp_line_rejections(rgbdslam_ctx *ctx, unsigned int *rejections);
-/* Debug: three numerators a3[3i..3i+2] divided by d[i] through the library's shared-reciprocal division (the normals'
- * x / r, y / r, z / r; csrc/device_fns.hpp) and through the compiler's IEEE division, for tests that compare the two. */
-int rgbdslam_debug_div3(rgbdslam_ctx *ctx, const float *a3_dev, const float *d_dev, float *q_shared_dev,
-                        float *q_ieee_dev, size_t N);
 /* Debug: give-up time of the device-side waits in 10 ns ticks (default 5 000 000 = 50 ms; 0 = every waiter leaves at once). */
 int rgbdslam_debug_set_icp_timeout(rgbdslam_ctx *ctx, int ticks);
 

@@ -17,42 +17,6 @@ __device__ __forceinline__ F3 vertex_from_depth(uint16_t d, int i, int j, const 
     return r;
 }
 
-// ---- IEEE f32 division of several numerators by ONE denominator --------------------------------------------------------
-// The compiler's correctly rounded a / d on gfx950 is v_div_scale x2, v_rcp, two fmas that refine the reciprocal, a
-// multiply, four fmas that refine the quotient (the last one v_div_fmas) and v_div_fixup: 11 instructions.  When d and a are
-// in a range where v_div_scale changes nothing (no scaling: |d| and |a| in [2^-40, 2^40], or a == 0 -- the ISA scales only for
-// denormal operands / results and exponent differences >= 96) that sequence is plain arithmetic on d, a and rcp(d), and the
-// reciprocal part (3 instructions) does not depend on the numerator: three quotients cost 3 + 3 x 6 instead of 3 x 11, bit
-// for bit the same.  Outside the range (any active lane) the wave takes the compiler's division.  tests/test_gpu_kernels.py
-// test_shared_denominator_division compares the two over random and edge-case operands.
-__device__ __forceinline__ int div_plain_range(float x) {
-    const float a = __builtin_fabsf(x);
-    return (a >= 0x1p-40f) & (a <= 0x1p40f);
-}
-__device__ __forceinline__ int div_plain_numerator(float x) { return (x == 0.0f) | div_plain_range(x); }
-__device__ __forceinline__ float div_refined_rcp(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-}
-__device__ __forceinline__ float div_by_rcp(float a, float d, float r) {
-    float q = a * r;
-    float e = __builtin_fmaf(-d, q, a);
-    q = __builtin_fmaf(e, r, q);
-    e = __builtin_fmaf(-d, q, a);
-    q = __builtin_fmaf(e, r, q);
-    return __builtin_amdgcn_div_fixupf(q, d, a);
-}
-__device__ __forceinline__ void div3_shared(float a0, float a1, float a2, float d, float &q0, float &q1, float &q2) {
-    const int plain = div_plain_range(d) & div_plain_numerator(a0) & div_plain_numerator(a1) & div_plain_numerator(a2);
-    if (__ballot(!plain) == 0ull) {
-        const float r = div_refined_rcp(d);
-        q0 = div_by_rcp(a0, d, r); q1 = div_by_rcp(a1, d, r); q2 = div_by_rcp(a2, d, r);
-    } else {
-        q0 = a0 / d; q1 = a1 / d; q2 = a2 / d;
-    }
-}
-
 // ---- D1/Kernel.cu:123-307 NormalKernel ------------------------------------------------------------
 // one of the four triangles around the pixel: normalised cross((a-p),(b-p)); returns 1 if counted
 __device__ __forceinline__ int tri_normal(F3 p, F3 a, F3 b, F3 &o) {
@@ -67,7 +31,7 @@ __device__ __forceinline__ int tri_normal(F3 p, F3 a, F3 b, F3 &o) {
         o.x = cx; o.y = cy; o.z = cz;
         if (nn != 0.0f) {
             float r = __builtin_sqrtf(nn);
-            div3_shared(cx, cy, cz, r, o.x, o.y, o.z);
+            o.x = cx / r; o.y = cy / r; o.z = cz / r;
             return 1;
         }
     }
@@ -83,13 +47,14 @@ __device__ __forceinline__ F3 normal_from_cross(F3 p, F3 dn, F3 up, F3 rt, F3 lf
     tot += tri_normal(p, lf, dn, n4);
     if (tot == 0) return z;
     float ft = (float)tot;
-    float a0, a1, a2;
-    div3_shared(((n1.x + n2.x) + n3.x) + n4.x, ((n1.y + n2.y) + n3.y) + n4.y, ((n1.z + n2.z) + n3.z) + n4.z, ft, a0, a1, a2);
+    float a0 = (((n1.x + n2.x) + n3.x) + n4.x) / ft;
+    float a1 = (((n1.y + n2.y) + n3.y) + n4.y) / ft;
+    float a2 = (((n1.z + n2.z) + n3.z) + n4.z) / ft;
     float nn = __builtin_sqrtf((a0 * a0 + a1 * a1) + a2 * a2);
     if (nn == 0.0f) return z;
     F3 r;
-    if (inverse) div3_shared(-a0, -a1, -a2, nn, r.x, r.y, r.z);
-    else div3_shared(a0, a1, a2, nn, r.x, r.y, r.z);
+    if (inverse) { r.x = (-a0) / nn; r.y = (-a1) / nn; r.z = (-a2) / nn; }
+    else { r.x = a0 / nn; r.y = a1 / nn; r.z = a2 / nn; }
     return r;
 }
 __device__ __forceinline__ F3 normal_global(const float *__restrict__ VMap, int i, int j, int n, int m, int inverse) {

@@ -271,26 +271,3 @@ extern "C" int rgbdslam_bilateral_depth(rgbdslam_ctx *ctx, uint16_t *dst, size_t
     HIP_TRY(hipGetLastError());
     return 0;
 }
-
-// ---- debug: the shared-denominator division of device_fns.hpp next to the compiler's, element by element -------------
-__global__ void k_debug_div3(const float *__restrict__ a, const float *__restrict__ d, float *__restrict__ q_shared,
-                             float *__restrict__ q_ieee, size_t N) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const float a0 = a[3 * i], a1 = a[3 * i + 1], a2 = a[3 * i + 2], dd = d[i];
-    float q0, q1, q2;
-    div3_shared(a0, a1, a2, dd, q0, q1, q2);
-    q_shared[3 * i] = q0; q_shared[3 * i + 1] = q1; q_shared[3 * i + 2] = q2;
-    float e0 = a0, e1 = a1, e2 = a2, ed = dd;
-    asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(ed));      // (keeps the two computations apart)
-    q_ieee[3 * i] = e0 / ed; q_ieee[3 * i + 1] = e1 / ed; q_ieee[3 * i + 2] = e2 / ed;
-}
-extern "C" int rgbdslam_debug_div3(rgbdslam_ctx *ctx, const float *a3_dev, const float *d_dev, float *q_shared_dev, float *q_ieee_dev,
-                                   size_t N) {
-    if (!ctx || !a3_dev || !d_dev || !q_shared_dev || !q_ieee_dev) return RGBDSLAM_E_ARG;
-    if (N == 0) return 0;
-    if (N > 0x7FFFFFFFull * 256ull) return RGBDSLAM_E_LIMIT;
-    KLAUNCH(ctx, k_debug_div3, dim3((unsigned)((N + 255) / 256)), dim3(256), a3_dev, d_dev, q_shared_dev, q_ieee_dev, N);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}

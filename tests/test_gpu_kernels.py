@@ -1033,48 +1033,3 @@ def test_rider_entry_points_equal_separate_calls(ctx, pkg, orc, pair, synth, tra
     if not tracked:
         same(out[1][0], pair["v1"])                                            # lost: model := input frame
         assert (out[1][14] == -1).all()
-
-
-def test_shared_denominator_division(ctx):
-    """div3_shared (csrc/device_fns.hpp: one refined reciprocal for three numerators, the compiler's own operation sequence
-    with the numerator-independent part shared) against the compiler's IEEE division, bit for bit: random operands over the
-    whole exponent range (so that waves take the fallback too), the magnitudes the normals see, zeros of both signs,
-    denormals, infinities, NaN, powers of two and all-ones mantissas."""
-    import ctypes as C
-    rng = np.random.default_rng(123)
-    N = 1 << 24
-    parts_a, parts_d = [], []
-    bits = rng.integers(0, 1 << 32, (N // 4, 3), dtype=np.uint64).astype(np.uint32)
-    parts_a.append(bits.view(np.float32))                                        # any bit pattern
-    parts_d.append(rng.integers(0, 1 << 32, N // 4, dtype=np.uint64).astype(np.uint32).view(np.float32))
-    d = np.exp2(rng.uniform(-30, 10, N // 2)).astype(np.float32)                  # what a normalisation sees: |a| <= d
-    a = (rng.uniform(-1, 1, (N // 2, 3)) * d[:, None]).astype(np.float32)
-    a[rng.random((N // 2, 3)) < 0.1] = 0.0
-    a[rng.random((N // 2, 3)) < 0.05] = -0.0
-    parts_a.append(a); parts_d.append(d)
-    special = np.array([0.0, -0.0, 1.0, -1.0, 2.0, 3.0, 4.0, 0.5, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-39, 1.1754944e-38,
-                        3.4028235e38, 2.0 ** -40, 2.0 ** 40, np.nextafter(np.float32(2.0 ** -40), np.float32(0)),
-                        np.nextafter(np.float32(2.0 ** 40), np.float32(np.inf)), np.float32(1.9999999), np.float32(1.0000001),
-                        2.0 ** -41, 2.0 ** 41, 1e-20, 1e20], np.float32)
-    g = np.stack(np.meshgrid(special, special, indexing="ij"), -1).reshape(-1, 2)
-    sa = np.stack([g[:, 0], np.roll(g[:, 0], 7), np.roll(g[:, 0], 13)], 1)
-    parts_a.append(sa); parts_d.append(g[:, 1].copy())
-    d = np.exp2(rng.integers(-45, 46, N // 8)).astype(np.float32) * np.where(rng.random(N // 8) < 0.5, 1.0, np.float32(1.9999999))
-    a = rng.standard_normal((N // 8, 3)).astype(np.float32) * np.exp2(rng.integers(-45, 46, (N // 8, 3))).astype(np.float32)
-    parts_a.append(a.astype(np.float32)); parts_d.append(d.astype(np.float32))    # around the range limits of the fast path
-    A = np.ascontiguousarray(np.concatenate(parts_a).astype(np.float32))
-    D = np.ascontiguousarray(np.concatenate(parts_d).astype(np.float32))
-    ga, gd = dev(A), dev(D)
-    qs, qi = torch.empty_like(ga), torch.empty_like(ga)
-    P = lambda t: C.c_void_p(t.data_ptr())
-    assert ctx.lib.rgbdslam_debug_div3(ctx._h, P(ga), P(gd), P(qs), P(qi), C.c_size_t(len(D))) == 0
-    ctx.synchronize()
-    hs, hi = host(qs).view(np.uint32), host(qi).view(np.uint32)
-    nan = np.isnan(host(qs)) & np.isnan(host(qi))
-    bad = (hs != hi) & ~nan
-    assert not bad.any(), "first mismatch: a=%r d=%r shared=%r ieee=%r" % (A[np.argwhere(bad)[0][0]], D[np.argwhere(bad)[0][0]],
-                                                                            host(qs)[np.argwhere(bad)[0][0]], host(qi)[np.argwhere(bad)[0][0]])
-    with np.errstate(all="ignore"):
-        ref = (A.astype(np.float64) / D.astype(np.float64)[:, None]).astype(np.float32)   # and both are the correctly rounded quotient
-    ok = (host(qi) == ref) | (np.isnan(ref) & np.isnan(host(qi)))
-    assert ok.all()
