@@ -406,7 +406,9 @@ __device__ __forceinline__ SegTileRegs seg3_request(const SegArgs &a, const int 
     R.eq0 = a.Eq[tid < 10 * min(a.nb_eq, SG_EQ_LDS) ? tid : 0];
     return R;
 }
-__device__ __forceinline__ void seg3_stage(const SegArgs &a, const SegTileRegs &R, const int tid, SegTileLds &S) {
+// returns whether the tile + 3 rings hold any label at all
+__device__ __forceinline__ bool seg3_stage(const SegArgs &a, const SegTileRegs &R, const int tid, SegTileLds &S) {
+    bool any = false;
     const int neq = 10 * min(a.nb_eq, SG_EQ_LDS);
     if (tid < neq) S.eq[tid] = R.eq0;
     for (int e = tid + TILE_W * TILE_H; e < neq; e += TILE_W * TILE_H) S.eq[e] = a.Eq[e];   // (more than 25 planes)
@@ -415,16 +417,28 @@ __device__ __forceinline__ void seg3_stage(const SegArgs &a, const SegTileRegs &
         const int e = tid + k * TILE_W * TILE_H;
         const int r = e / SG_W, c = e % SG_W;
         if (e < SG_H * SG_W) S.lab[r][c] = R.l[k];
-        if (R.queue[k] && R.l[k] == 0) S.qpos[atomicAdd(&S.qn, 1u)] = (unsigned short)(r * SG_WP + c);
+        // one LDS atomic per wave, not per pixel: a tile without labels queues all its 544
+        const bool push = R.queue[k] && R.l[k] == 0;
+        const unsigned long long pm = __ballot(push);
+        if (pm) {
+            const int lane = tid & 63;
+            unsigned int base = 0u;
+            if (lane == (int)__builtin_ctzll(pm)) base = atomicAdd(&S.qn, (unsigned int)__builtin_popcountll(pm));
+            base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(pm));
+            if (push) S.qpos[base + (unsigned int)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (unsigned short)(r * SG_WP + c);
+        }
+        any |= (e < SG_H * SG_W) && R.l[k] != 0;
     }
-    __syncthreads();
+    // labels only spread from labelled pixels, three steps at most: a tile whose 70 x 10 labels are all 0 stays that way
+    return __syncthreads_or(any ? 1 : 0) != 0;
 }
 // after seg3_stage.  Returns the label of the thread's own pixel after the third pass.
-__device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, const int j0, const int tid, SegTileLds &S) {
+__device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, const int j0, const int tid, SegTileLds &S,
+                                               const bool any_label) {
 #ifdef SEG3_NOQUEUE                                  // (timing experiments only: the passes never run)
     const int nq = 0;
 #else
-    const int nq = (int)S.qn;                        // uniform
+    const int nq = any_label ? (int)S.qn : 0;        // uniform
 #endif
     uint8_t *const L = &S.lab[0][0];
     if (nq > 0) {
@@ -588,8 +602,8 @@ __device__ __forceinline__ void segment3_claim_tile(const SegArgs &sg, const Mer
     int mk = mg.Mask_in[idx];
     asm volatile("" : "+v"(w_old), "+v"(mk));
     __syncthreads();
-    seg3_stage(sg, SR, tid, S);
-    const uint8_t mine = seg3_passes(sg, i0, j0, tid, S);
+    const bool any_label = seg3_stage(sg, SR, tid, S);
+    const uint8_t mine = seg3_passes(sg, i0, j0, tid, S, any_label);
     if (in) sg.out[idx] = mine;
     int newmask;
     const float w = merge_pixel(w_old, d, (uint8_t)mk, mg.c, newmask);

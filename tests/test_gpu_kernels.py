@@ -861,6 +861,7 @@ def test_segment_merge_claim_one_launch(ctx, pkg, orc, pair, synth, shape, nb, d
     if nb > 3:                                                 # the same plane under other labels: 3, 6, ... steps further away
         lab0 = np.where(lab0 > 0, lab0 + 3 * rng.integers(0, (nb - lab0.max()) // 3 + 1, (n, m)), 0).astype(np.uint8)
     lab0[n // 3:n // 3 + 12, m // 4:m // 4 + 90] = 0           # a block without labels (every pixel of some tiles is queued)
+    lab0[n // 2:n // 2 + 30, m // 8:m // 8 + 220] = 0          # a larger one: tiles whose 3 rings hold no label at all are skipped
     rgbd = crop(pair["rgbd0"]).copy()
     rgbd[..., 3][n // 2:] *= 1.02                               # a few merge branches
     mask = rng.integers(9, 60, (n, m)).astype(np.uint8)
