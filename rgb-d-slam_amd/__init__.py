@@ -405,6 +405,11 @@ class RG:
         measured slower than one stream at 640x480)."""
         _hchk(self.lib.slamhost_rg_set_overlap(self._h, int(on)), "set_overlap")
 
+    def set_overlap_mode(self, mode):
+        """Bits: 1 = frames are uploaded + preprocessed on a load stream (pays for host-fed frames: the copies run beside the
+        previous frame's kernels), 2 = Bump update on its own stream.  Before the first frame."""
+        _hchk(self.lib.slamhost_rg_set_overlap_mode(self._h, int(mode)), "set_overlap_mode")
+
     def history(self, first, count):
         """Poses of frames [first, first+count): rows of poseR(9, col-major) poset(3) tracked iterations level_iters 0."""
         import numpy as np

@@ -188,6 +188,8 @@ OffLineFrame::~OffLineFrame() {
     for (int k = 0; k < 2; k++) {
         if (_ready[k]) (void)hipEventDestroy(_ready[k]);
         if (_free[k]) (void)hipEventDestroy(_free[k]);
+        if (_sig_ready[k]) (void)hipFree(_sig_ready[k]);
+        if (_sig_free[k]) (void)hipFree(_sig_free[k]);
     }
 }
 
@@ -209,14 +211,29 @@ void OffLineFrame::AttachLoadStream(hipStream_t load_stream) {
     }
     if (_gradients) EnableGradients(true);
     for (int k = 0; k < 2; k++) {
-        if (!_ready[k]) hip_check(hipEventCreateWithFlags(&_ready[k], hipEventDisableTiming), "hipEventCreate");
-        if (!_free[k]) hip_check(hipEventCreateWithFlags(&_free[k], hipEventDisableTiming), "hipEventCreate");
+        if (_use_events) {
+            if (!_ready[k]) hip_check(hipEventCreateWithFlags(&_ready[k], hipEventDisableTiming), "hipEventCreate");
+            if (!_free[k]) hip_check(hipEventCreateWithFlags(&_free[k], hipEventDisableTiming), "hipEventCreate");
+        } else if (!_sig_ready[k]) {                           // signal memory comes in 8-byte allocations
+            hip_check(hipExtMallocWithFlags((void **)&_sig_ready[k], 8, hipMallocSignalMemory), "signal memory");
+            hip_check(hipExtMallocWithFlags((void **)&_sig_free[k], 8, hipMallocSignalMemory), "signal memory");
+            hip_check(hipMemset(_sig_ready[k], 0, 8), "hipMemset");
+            hip_check(hipMemset(_sig_free[k], 0, 8), "hipMemset");
+        }
     }
+}
+
+void OffLineFrame::wait_ready(hipStream_t consumer) {
+    if (!_load_stream) return;
+    if (_use_events) hip_check(hipStreamWaitEvent(consumer, _ready[_cur], 0), "wait for the preprocessed frame");
+    else hip_check(hipStreamWaitValue32(consumer, _sig_ready[_cur], _seq_ready[_cur], hipStreamWaitValueGte, 0xFFFFFFFFu),
+                   "wait for the preprocessed frame");
 }
 
 void OffLineFrame::release(hipStream_t consumer) {
     if (!_load_stream) return;
-    hip_check(hipEventRecord(_free[_cur], consumer), "hipEventRecord");
+    if (_use_events) hip_check(hipEventRecord(_free[_cur], consumer), "hipEventRecord");
+    else hip_check(hipStreamWriteValue32(consumer, _sig_free[_cur], ++_seq_free[_cur], 0), "hipStreamWriteValue32");
     _free_recorded[_cur] = true;
 }
 
@@ -224,7 +241,11 @@ void OffLineFrame::release(hipStream_t consumer) {
 void OffLineFrame::begin_load() {
     if (_load_stream && _loaded_once) {
         _cur ^= 1;
-        if (_free_recorded[_cur]) hip_check(hipStreamWaitEvent(_load_stream, _free[_cur], 0), "hipStreamWaitEvent");
+        if (_free_recorded[_cur]) {
+            if (_use_events) hip_check(hipStreamWaitEvent(_load_stream, _free[_cur], 0), "hipStreamWaitEvent");
+            else hip_check(hipStreamWaitValue32(_load_stream, _sig_free[_cur], _seq_free[_cur], hipStreamWaitValueGte, 0xFFFFFFFFu),
+                           "hipStreamWaitValue32");
+        }
     }
     _loaded_once = true;
 }
@@ -304,7 +325,10 @@ void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
     }
     if (_load_stream) {
         check(rgbdslam_set_stream(_ctx, main), "set_stream");
-        if (!rc) hip_check(hipEventRecord(_ready[_cur], _load_stream), "hipEventRecord");
+        if (!rc) {
+            if (_use_events) hip_check(hipEventRecord(_ready[_cur], _load_stream), "hipEventRecord");
+            else hip_check(hipStreamWriteValue32(_load_stream, _sig_ready[_cur], ++_seq_ready[_cur], 0), "hipStreamWriteValue32");
+        }
     }
     check(rc, "frame preprocess");
 }
@@ -638,7 +662,7 @@ RG::~RG() {
 // before the first frame: the fused pipeline loads through the auxiliary stream into alternating buffer sets
 void RG::configure_streams() {
     const char *e = getenv("RGBDSLAM_OVERLAP_MODE");
-    if (e) _overlap_mode = atoi(e);
+    if (e && !_overlap_mode_set) _overlap_mode = atoi(e);
     if (_count == 1 && fused && overlap && (_overlap_mode & 1) && !_frame->load_stream()) _frame->AttachLoadStream(_load_stream);
 }
 
@@ -1059,7 +1083,7 @@ int RG::StepAsync() {
     hipStream_t main = ctx_stream(_ctx);
     const bool ovl = _frame->load_stream() != nullptr;
     const bool ov = fused && overlap && (_overlap_mode & 2);
-    if (ovl) hip_check(hipStreamWaitEvent(main, _frame->ready_event(), 0), "wait for the preprocessed frame");
+    if (ovl) _frame->wait_ready(main);
     if (first) _predicted_frame->ReseedFused(nullptr, 1, _frame);                   // GP-demo.cpp:164-167
     rgbdslam_icp_params prm = icp_params();
     const int slot = frames_done % HISTORY_CAP;
@@ -1372,6 +1396,15 @@ int slamhost_rg_set_overlap(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     if (((RG *)rg)->_count != 1) return RGBDSLAM_E_STATE;
     ((RG *)rg)->overlap = on != 0;
+    return 0;
+}
+// mode bits: 1 = frames are loaded (uploaded + preprocessed) on the load stream, into alternating buffer sets; 2 = the Bump
+// update runs on the update stream.  0 = everything on one stream.  Before the first frame only.
+int slamhost_rg_set_overlap_mode(void *rg, int mode) {
+    if (!rg || mode < 0 || mode > 3) return RGBDSLAM_E_ARG;
+    if (((RG *)rg)->_count != 1) return RGBDSLAM_E_STATE;
+    ((RG *)rg)->overlap = mode != 0;
+    ((RG *)rg)->set_overlap_mode(mode);
     return 0;
 }
 int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {

@@ -129,12 +129,12 @@ public:
     float *getGy() { return _Gy[_cur].p; }
     const uint16_t *depth() const { return _depth_cur[_cur]; }
     size_t depth_pitch() const { return _depth_pitch[_cur]; }
-    // Overlap: loads go to `load_stream` and alternate between the two buffer sets.  ready_event() = the current
+    // Overlap: loads go to `load_stream` and alternate between the two buffer sets.  wait_ready(consumer) = the current
     // set is preprocessed (the consumer stream waits on it); release(consumer) = the consumer's work enqueued
     // so far is the last that reads the current set (the load that next reuses the set waits on it).
     void AttachLoadStream(hipStream_t load_stream);
     hipStream_t load_stream() const { return _load_stream; }
-    hipEvent_t ready_event() const { return _ready[_cur]; }
+    void wait_ready(hipStream_t consumer);                         // the consumer stream waits for the current set's maps
     void release(hipStream_t consumer);
 private:
     void begin_load();
@@ -148,7 +148,14 @@ private:
     DevBuf<uint16_t> _depth_filtered[2];
     void filter_depth();
     hipStream_t _load_stream = nullptr;
+    // The two streams are ordered by stream VALUE operations on two words of signal memory per buffer set (ready: written
+    // by the load stream, awaited by the consumer; free: the reverse), sequence numbers counting up: measured on this
+    // system (tools/microbench/stream_sync.hip) an event record + wait costs ~16 us per hand-over, a value write + wait ~6.
+    // RGBDSLAM_STREAM_EVENTS=1 selects events.
+    bool _use_events = getenv("RGBDSLAM_STREAM_EVENTS") != nullptr;
     hipEvent_t _ready[2] = {nullptr, nullptr}, _free[2] = {nullptr, nullptr};
+    uint32_t *_sig_ready[2] = {nullptr, nullptr}, *_sig_free[2] = {nullptr, nullptr};
+    uint32_t _seq_ready[2] = {0, 0}, _seq_free[2] = {0, 0};
     bool _free_recorded[2] = {false, false};
     bool _loaded_once = false;
     struct { const uint16_t *depth = nullptr; size_t depth_pitch = 0; const uint8_t *bgr = nullptr; size_t bgr_pitch = 0; bool valid = false, other = false; } _pre;
@@ -345,6 +352,10 @@ private:
     hipEvent_t _ev_merged = nullptr, _ev_updated = nullptr;
     bool _update_pending = false;
     int _overlap_mode = 3;   // bit 0: loads on the load stream, bit 1: Bump update on the update stream
+    bool _overlap_mode_set = false;
+public:
+    void set_overlap_mode(int mode) { _overlap_mode = mode; _overlap_mode_set = true; }
+private:
     DevBuf<int32_t> _status_dev;
     float *_pinned = nullptr;   // 24 floats pose state + 4 ints status
     rgbdslam_pose_block *_pb_dev = nullptr, *_pb_host = nullptr;   // device block + pinned mirror
