@@ -509,6 +509,9 @@ def main():
                     help="RG::Finish's periodic dump + plane re-detection cycle in the timed region: every P frames (reference: 100; "
                          "default 0 = off, see DESIGN.md section 6); the first detection after frame 30 always runs, in the set-up")
     ap.add_argument("--no-large-kernels", action="store_true", help="skip the config-3/config-4-size kernel rooflines")
+    ap.add_argument("--no-h2d", action="store_true",
+                    help="skip the PCIe-inclusive measurement (two streams ordered by stream value operations: a counter-collecting "
+                         "profiler that serialises dispatches across queues never lets the producer stream run)")
     ap.add_argument("--profile-in-timed-region", action="store_true",
                     help="record the roofline events inside the timed region instead of in a second pass")
     args = ap.parse_args()
@@ -677,7 +680,7 @@ def main():
 
     # ---- PCIe-inclusive rate (never `value`): host-resident frames through RG::LoadFrame, 1.5 MB H2D per frame, pinned ----
     value_with_h2d = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_h2d:
         hd = [torch.from_numpy(p[0]).pin_memory() for p in pool]
         hb = [torch.from_numpy(p[1]).pin_memory() for p in pool]
         nh = min(args.steps, 300)
@@ -695,19 +698,22 @@ def main():
         one_stream = round(nh / (time.perf_counter() - h0), 2)
         # (b) a pipeline of its own with the loads on a second stream (RG overlap mode 1: upload + preprocessing of frame
         # f+1 beside the kernels of frame f, the two streams ordered by stream value operations): what host-fed callers use
-        rg2 = pkg.RG(n, m, calib, device=local, stream=stream.cuda_stream)
-        rg2.set_overlap_mode(1)
-        if args.icp_loop:
-            rg2.set_icp_loop(True)
-        rg2.set_finish(True, 30, 0)
-        run_h2d(rg2, order[:SETUP])
-        run_h2d(rg2, order[SETUP:SETUP + 20])
-        h0 = time.perf_counter()
-        run_h2d(rg2, order[SETUP + 20:SETUP + 20 + nh])
-        two_streams = round(nh / (time.perf_counter() - h0), 2)
-        if rg2.finish_stats()["planes"] < 3:
-            raise SystemExit("host-fed pipeline: plane detection failed")
-        rg2.close()
+        two_streams = 0.0
+        under_profiler = any(k.startswith("ROCPROF") for k in os.environ)      # see --no-h2d: (b) can deadlock under counter collection
+        if not under_profiler:
+            rg2 = pkg.RG(n, m, calib, device=local, stream=stream.cuda_stream)
+            rg2.set_overlap_mode(1)
+            if args.icp_loop:
+                rg2.set_icp_loop(True)
+            rg2.set_finish(True, 30, 0)
+            run_h2d(rg2, order[:SETUP])
+            run_h2d(rg2, order[SETUP:SETUP + 20])
+            h0 = time.perf_counter()
+            run_h2d(rg2, order[SETUP + 20:SETUP + 20 + nh])
+            two_streams = round(nh / (time.perf_counter() - h0), 2)
+            if rg2.finish_stats()["planes"] < 3:
+                raise SystemExit("host-fed pipeline: plane detection failed")
+            rg2.close()
         value_with_h2d = {"value": max(one_stream, two_streams), "unit": "frames/s", "frames": nh,
                           "h2d_bytes_per_frame": n * m * 5, "one_stream": one_stream, "load_stream": two_streams,
                           "note": "the same pipeline fed from pinned host memory (u16 depth + BGR8 uploaded per frame by RG::LoadFrame, "

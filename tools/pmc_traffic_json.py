@@ -22,7 +22,7 @@ for e in out.values():
             del e[k]
     e["fetch"], e["write"] = int(round(e["fetch"])), int(round(e["write"]))
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh) on: bench.py --cpu-frames 0 "
-                 "--steps 40 --warmup 5 --no-large-kernels; unit of the counters: KB; raw values, no gfx950 x2 FETCH correction "
+                 "--steps 40 --warmup 5 --no-large-kernels --no-h2d; unit of the counters: KB; raw values, no gfx950 x2 FETCH correction "
                  "applied (the accesses are 4-16 B per lane, uncalibrated per MI355X_MICROARCH.md)",
        "bytes_per_launch": out}
 json.dump(doc, open(base + "_pmc_traffic.json", "w"), indent=1)
