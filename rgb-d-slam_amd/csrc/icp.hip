@@ -210,21 +210,32 @@ __device__ __forceinline__ bool icp_lines_intact(unsigned int word, int lane) {
 
 // tr = this wave's LDS scratch [27][8]; returns the finished sum of term `lane` in lanes 0..26
 __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
-    const bool row_head = (lane & 7) == 0;
+    const int col = lane & 7;
     const int r = lane >> 3;
-    float x[27];
+    float s[27];
 #pragma unroll
-    for (int k = 0; k < 27; k++) x[k] = add_shl<4>(v[k]);      // level by level: independent DPP chains interleave
+    for (int k = 0; k < 27; k++) s[k] = add_shl<4>(v[k]);      // level by level: independent DPP chains interleave
+    // After the first level only columns 0..3 of a term matter: two terms share a register from here on, term 2j in
+    // columns 0..3 and term 2j+1 moved into columns 4..7 (one masked DPP move), so the remaining two levels and the
+    // transposing stores run on 14 registers instead of 27.  The pairs added are the same (c | c+2, then c | c+1, for
+    // c = 0, 1 of either half), so are the bits.
+    float x[14];
 #pragma unroll
-    for (int k = 0; k < 27; k++) x[k] = add_shl<2>(x[k]);
+    for (int j = 0; j < 13; j++)      // row_shr:4 into banks 1 and 3 (lanes 4..7 and 12..15 of a row); the other lanes keep s[2j]
+        x[j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(s[2 * j]), __float_as_int(s[2 * j + 1]), 0x110 + 4, 0xF, 0xA, false));
+    x[13] = s[26];
 #pragma unroll
-    for (int k = 0; k < 27; k++) {
-        x[k] = add_shl<1>(x[k]);
-        asm volatile("" : "+v"(x[k]));                          // or the add is sunk into the branch below and its DPP operand becomes a separate move
+    for (int j = 0; j < 14; j++) x[j] = add_shl<2>(x[j]);
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        x[j] = add_shl<1>(x[j]);
+        asm volatile("" : "+v"(x[j]));                          // or the add is sunk into the branch below and its DPP operand becomes a separate move
     }
-    if (row_head) {
+    if ((col & 3) == 0) {                                       // column 0 holds term 2j, column 4 term 2j+1
+        float *dst = tr + (col >> 2) * 8 + r;
 #pragma unroll
-        for (int k = 0; k < 27; k++) tr[k * 8 + r] = x[k];
+        for (int j = 0; j < 13; j++) dst[2 * j * 8] = x[j];
+        if (col == 0) tr[26 * 8 + r] = x[13];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
