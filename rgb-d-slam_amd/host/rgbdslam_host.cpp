@@ -252,6 +252,7 @@ void OffLineFrame::begin_load() {
 
 void OffLineFrame::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
     size_t P = (size_t)_n * _m;
+    if (_pre.valid && !_pre.other) _pre.valid = false;       // this load overwrites the set a rider preprocessed in place
     begin_load();
     hipStream_t s = _load_stream ? _load_stream : ctx_stream(_ctx);
     if (!_depth_dev_test[_cur].p) { _depth_dev_test[_cur].alloc(P); _color_dev_test[_cur].alloc(3 * P); }   // (after a set switch)
