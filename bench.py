@@ -206,6 +206,9 @@ def check_line(d, base_metric=None):
             assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "frames/s" and c["value"] > 0 and c["sample"]
         if d.get("value_with_h2d"):
             assert 0 < d["value_with_h2d"]["value"] <= 1.05 * d["value"]
+        if d.get("parity_in_run") is not None:        # lines since round 3: the run carries its own parity evidence
+            q = d["parity_in_run"]
+            assert q["bit_exact"] is True and q["frames"] > 0 and q["max_abs_pose_diff"] <= q["tolerance"] == 1e-5
     for k in d.get("hbm_bound_kernels") or []:
         assert abs(k["frac"] - k["achieved"] / HBM_PEAK_GBS) < 1e-3 and 0 < k["frac_of_measured_stream"] < 1.5
         gbs = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
@@ -601,7 +604,7 @@ def main():
         raise SystemExit("plane detection found %d planes after the set-up frames: result invalid" % fs["planes"])
     pos = SETUP
     if args.finish_period:
-        rg.set_finish(True, 30, args.finish_period)
+        rg.set_finish(True, 30, args.finish_period, reset_without_dump=True)   # no dump directory: the cycle's cost without file I/O
     run(order[pos:pos + args.warmup])
     pos += args.warmup
     if args.profile_in_timed_region:
@@ -624,6 +627,9 @@ def main():
         raise SystemExit("the persistent ICP kernel gave up waiting for its grid (is another process using this GPU?): result invalid")
     if tracked != args.steps:
         raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
+    # poses of the warm-up and the timed frames as the device left them (compared with the oracle's in the cpu_baseline leg)
+    gpu_first = SETUP
+    gpu_hist = rg.history(gpu_first, min(args.warmup + args.steps, max(0, 3 * args.cpu_frames))) if rank == 0 and world == 1 and args.cpu_frames > 0 else None
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches ----
     level_iters = [0, 0, 0]
@@ -726,38 +732,65 @@ def main():
                                   "stream (RG overlap mode 1), one_stream = everything in order on one"}
 
     # ---- CPU baseline: the oracle's display() loop on a bounded sample of the same sequence ----
-    cpu = cpu_all = None
+    cpu = cpu_all = parity = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import oracle as orc
-        ref = orc.Slam(n, m, calib)
-        ref.set_finish(True, 30, 0)
-        for i in order[:SETUP]:                      # the same set-up: seed + detection after frame 30
-            ref.step(*pool[i])
-        c0 = time.perf_counter()
-        for i in order[SETUP:SETUP + args.cpu_frames]:
-            ref.step(*pool[i])
-        cdt = time.perf_counter() - c0
-        ref.close()
+        # parity in the run: the oracle steps over the very frames the GPU was timed on (set-up, warm-up, timed region); every
+        # pose it produces is compared with the GPU's history entry of the same frame, bit for bit.  A mismatch is fatal.
+        checked = {"frames": 0, "timed": 0, "max_abs": 0.0, "bad": []}
+
+        def check_pose(f, st, R, t):
+            k = f - gpu_first
+            if gpu_hist is None or k < 0 or k >= len(gpu_hist):
+                return
+            h = gpu_hist[k]
+            d = max(float(np.abs(h[:9] - R).max()), float(np.abs(h[9:12] - t).max()))
+            checked["max_abs"] = max(checked["max_abs"], d)
+            checked["frames"] += 1
+            checked["timed"] += 1 if k >= args.warmup else 0
+            if int(h[12]) != (1 if st else 0) or not (np.array_equal(h[:9], R) and np.array_equal(h[9:12], t)):
+                checked["bad"].append(f)
+
+        def oracle_pass(frames, check):
+            ref = orc.Slam(n, m, calib)
+            ref.set_finish(True, 30, 0)
+            for i in order[:SETUP]:                  # the same set-up: seed + detection after frame 30
+                ref.step(*pool[i])
+            if args.finish_period:
+                ref.set_finish(True, 30, args.finish_period)
+            c0 = time.perf_counter()
+            for f in range(SETUP, SETUP + frames):
+                st = ref.step(*pool[order[f]])
+                if check:
+                    R_, t_ = ref.pose()
+                    check_pose(f, st, R_, t_)
+            cdt_ = time.perf_counter() - c0
+            ref.close()
+            return cdt_
+
+        cdt = oracle_pass(args.cpu_frames, False)
         cpu = {"value": round(args.cpu_frames / cdt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same %dx%d sequence, oracle display() loop (scalar C, -O2, 1 thread)"
                          % (args.cpu_frames, m, n)}
-        # the same sources with OpenMP over rows / blocks on the host cores this job may use
+        # the same sources with OpenMP over rows / blocks on the host cores this job may use.  This pass is
+        # long enough to run through the warm-up into the timed region, so it carries the pose comparison (the pose reads cost
+        # microseconds per frame; results of the two builds are bit-identical, tests/test_oracle_omp.py)
         orc.use_openmp(True)
         try:
-            ref = orc.Slam(n, m, calib)
-            ref.set_finish(True, 30, 0)
-            for i in order[:SETUP]:
-                ref.step(*pool[i])
             nf = 3 * args.cpu_frames
-            c0 = time.perf_counter()
-            for i in order[SETUP:SETUP + nf]:
-                ref.step(*pool[i])
-            cdt = time.perf_counter() - c0
-            ref.close()
+            cdt = oracle_pass(nf, True)
             cpu_all = {"value": round(nf / cdt, 3), "unit": "frames/s", "cores": orc.threads(), "kind": "port",
                        "sample": "%d frames of the same sequence, the same oracle sources built with -fopenmp (bit-identical results)" % nf}
         finally:
             orc.use_openmp(False)
+        parity = {"frames": checked["frames"], "timed_frames": checked["timed"], "bit_exact": not checked["bad"],
+                  "max_abs_pose_diff": checked["max_abs"], "tolerance": 1e-5,
+                  "what": "pose history (poseR, poset, tracked flag) of the warm-up + timed frames on the GPU vs the oracle's display() loop "
+                          "over the same frames, in this run"}
+        if checked["bad"] or checked["frames"] == 0:
+            print(json.dumps({"parity_in_run": parity, "first_bad_frames": checked["bad"][:8]}), file=sys.stderr, flush=True)
+            raise SystemExit("parity_in_run failed: the GPU pose history differs from the oracle's on %d of %d frames: result invalid"
+                             % (len(checked["bad"]), checked["frames"]))
 
     large = probe = None
     if rank == 0 and world == 1 and not args.no_large_kernels:
@@ -776,7 +809,7 @@ def main():
                           "rows": n, "cols": m, "sequences": world, "frames_resident_in_hbm": True,
                           "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame",
                           "finish_period": args.finish_period},
-               "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
+               "parity_in_run": parity, "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
         print(json.dumps(check_line(out)), flush=True)
     rg.close()
     if world > 1:

@@ -522,11 +522,19 @@ class RG:
         D1/Frame.cpp:50-54): cv::bilateralFilter(depth, 5, 100.0, 100.0) before the vertex map is computed."""
         _hchk(self.lib.slamhost_rg_set_bilateral(self._h, int(on)), "set_bilateral")
 
-    def set_finish(self, enabled=True, first_after=30, period=100, save_dir=None, min_size=-1, min_normals=-1):
+    def set_finish(self, enabled=True, first_after=30, period=100, save_dir=None, min_size=-1, min_normals=-1,
+                   reset_without_dump=False):
         """RG::Finish schedule (D1/RG.cpp:149-271): first plane detection when _count > first_after, then every `period`
-        frames dump (into save_dir, if given) + plane reset + re-detection; period 0 = never."""
+        frames dump into save_dir + plane reset + re-detection; period 0 = never.  As in RG.cpp:177-187 a due period is
+        skipped altogether while save_dir holds a Dummy.txt -- and when there is no save_dir, unless reset_without_dump
+        says that the fused planes may be thrown away unsaved."""
         _hchk(self.lib.slamhost_rg_set_finish(self._h, int(enabled), int(first_after), int(period),
                                               os.fsencode(save_dir) if save_dir else None, int(min_size), int(min_normals)), "set_finish")
+        _hchk(self.lib.slamhost_rg_set_finish_reset_without_dump(self._h, int(reset_without_dump)), "set_finish_reset_without_dump")
+
+    def finish_skipped(self):
+        """Periods of RG::Finish that were due but skipped because nothing could be saved."""
+        return self.lib.slamhost_rg_finish_skipped(self._h)
 
     def finish_stats(self):
         out = (C.c_int * 4)()

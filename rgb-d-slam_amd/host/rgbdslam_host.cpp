@@ -1000,6 +1000,22 @@ void RG::Finish() {
     const bool first_due = _first_in && _count > finish_first_after;                  // RG.cpp:154
     const bool period_due = !first_due && finish_period > 0 && (_count % finish_period) == 0;   // RG.cpp:187
     if (!first_due && !period_due) return;
+    // RG.cpp:177-187: `(_count % 100) == 0 && _finished && ok2Save` gates the WHOLE periodic block -- while a file Dummy.txt sits
+    // in the data directory the reference neither dumps, nor resets the plane set, nor detects again.  The reference always
+    // has somewhere to save to (a hard-coded directory, RG.cpp:229); here no save_dir means that nothing CAN be saved, and
+    // throwing the fused planes away without a dump must be asked for (finish_reset_without_dump: bench.py's
+    // --finish-period, the oracle's schedule) -- otherwise such a period is skipped like one with a Dummy.txt.
+    // Host-decidable, so a skipped period does not even drain the queue.
+    bool can_dump = false;
+    if (period_due) {
+        can_dump = !save_dir.empty();
+        if (can_dump) {
+            FILE *f = fopen((save_dir + "/Dummy.txt").c_str(), "r");
+            if (f) { can_dump = false; fclose(f); }
+        }
+        const bool ok2Save = can_dump || (save_dir.empty() && finish_reset_without_dump);
+        if (!ok2Save) { finish_skipped++; return; }
+    }
     StageTimer st_cycle("RG::Finish (whole)");
     if (fused) {
         StageTimer st("Sync (drain the queue)");
@@ -1011,14 +1027,9 @@ void RG::Finish() {
         finish_detections++;
         return;
     }
-    bool ok2Save = !save_dir.empty();
-    if (ok2Save) {                                                                    // RG.cpp:177-184
-        FILE *f = fopen((save_dir + "/Dummy.txt").c_str(), "r");
-        if (f) { ok2Save = false; fclose(f); }
-    }
     _poseRPrev = _poseR;                                                              // RG.cpp:189-190
     _posetPrev = _poset;
-    if (ok2Save) { StageTimer st("SaveModel"); SaveModel(save_dir.c_str(), _indx); finish_dumps++; }   // RG.cpp:209-232 (+ SaveThread, RG.cpp:16-59)
+    if (can_dump) { StageTimer st("SaveModel"); SaveModel(save_dir.c_str(), _indx); finish_dumps++; }   // RG.cpp:209-232 (+ SaveThread, RG.cpp:16-59)
     _indx++;                                                                          // RG.cpp:234
     DetectPlanes();                                                                   // RG.cpp:253-268: tables freed, planes re-detected
     finish_detections++;
@@ -1590,7 +1601,9 @@ int slamhost_rg_detect_planes(void *rg, int min_size, int min_normals, int *nb) 
     return 0;
 }
 // RG::Finish schedule: enabled, first detection when _count > first_after, dump + re-detection when _count % period == 0
-// (period 0 = never); save_dir NULL / "" = no dump; min_size / min_normals >= 0 override MIN_SIZE_PLAN / 1000 (small images)
+// (period 0 = never); save_dir NULL / "" = nowhere to dump: a due period is then skipped like one that finds a Dummy.txt
+// (RG.cpp:177-187) unless slamhost_rg_set_finish_reset_without_dump allows the reset; min_size / min_normals >= 0 override
+// MIN_SIZE_PLAN / 1000 (small images)
 // optional bilateral stage of OffLineFrame::LoadFrame (Frame.cpp:50-54, commented out in the reference): default off
 int slamhost_rg_set_bilateral(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
@@ -1606,6 +1619,14 @@ int slamhost_rg_set_finish(void *rg, int enabled, int first_after, int period, c
     if (min_normals >= 0) r->min_normals_plan = min_normals;
     return 0;
 }
+// 1: a period that is due with no save_dir still resets the plane set and detects again (nothing is dumped: the fused planes
+// are lost -- what a benchmark of the cycle or a comparison with the oracle's schedule wants); default 0
+int slamhost_rg_set_finish_reset_without_dump(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    ((RG *)rg)->finish_reset_without_dump = on != 0;
+    return 0;
+}
+int slamhost_rg_finish_skipped(void *rg) { return rg ? ((RG *)rg)->finish_skipped : -1; }
 // [0] detections run by Finish, [1] dumps written, [2] current plane count, [3] _indx
 int slamhost_rg_finish_stats(void *rg, int *out4) {
     if (!rg || !out4) return RGBDSLAM_E_ARG;

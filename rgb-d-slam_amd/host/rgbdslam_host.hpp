@@ -284,9 +284,13 @@ public:
     int DetectPlanes();
     // RG::Finish (RG.cpp:149-271), step 12 of display() (GP-demo.cpp:274): the first plane detection once _count > 30, then
     // every 100 frames the dump of the model (SaveModel into save_dir; synchronous -- the reference's Win32 SaveThread is
-    // out of scope -- and skipped when save_dir is empty or holds a file Dummy.txt, RG.cpp:177-184), the reset of the plane
-    // set and a new detection.  Step() / StepAsync() call it; a frame whose tracking was lost skips it (GP-demo.cpp:196).
+    // out of scope), the reset of the plane set and a new detection.  As in RG.cpp:177-187 the WHOLE periodic block is
+    // skipped while save_dir holds a file Dummy.txt; it is also skipped when there is no save_dir (nothing could be dumped, and
+    // the fused planes are not thrown away silently) unless finish_reset_without_dump is set.
+    // Step() / StepAsync() call it; a frame whose tracking was lost skips it (GP-demo.cpp:196).
     void Finish();
+    bool finish_reset_without_dump = false;
+    int finish_skipped = 0;                                        // periods that were due but could not be saved
     bool finish_enabled = true;
     int finish_first_after = 30, finish_period = 100;              // RG.cpp:154,187
     std::string save_dir;

@@ -59,3 +59,5 @@ def test_live_bench_run_passes_the_contract():
     d = bench.check_line(json.loads(lines[0]), json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"])
     assert d["roofline"]["kernel"] == "k_icp_loop" and d["roofline"]["traffic_source"]["file"].startswith("profiles/")
     assert d["value_with_h2d"]["value"] > 500 and d["cpu_baseline"]["cores"] == 1
+    q = d["parity_in_run"]                           # 3 x 2 oracle frames: the 5 warm-up frames and the first timed one
+    assert q["bit_exact"] is True and q["frames"] == 6 and q["timed_frames"] == 1 and q["max_abs_pose_diff"] == 0.0
