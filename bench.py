@@ -423,6 +423,12 @@ def run_rows(args, env):
         ctx.alloc_buffers((n + 7) // 8, (m + 7) // 8)
         prm = pkg.icp_params()
         aligner = multigpu.ShardedAligner(ctx, prm, n, m, rank, world, exchange=args.exchange)
+        # test hook: RGBDSLAM_BENCH_XCHG_DELAY="rank:ticks" makes that rank's tail fall behind (ticks x 10 ns) between its
+        # publication and its first poll in every exchanged iteration (the double-buffered slots must absorb it)
+        dl = os.environ.get("RGBDSLAM_BENCH_XCHG_DELAY")
+        if dl and int(dl.split(":")[0]) == rank:
+            if ctx.lib.rgbdslam_debug_set_exchange_delay(ctx._h, int(dl.split(":")[1])) != 0:
+                raise SystemExit("rgbdslam_debug_set_exchange_delay refused %s" % dl)
         I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
         start = dev(np.concatenate([I, z, I, z]).astype(np.float32))
         state = start.clone()

@@ -155,6 +155,9 @@ int rgbdslam_set_icp_line_check(rgbdslam_ctx *ctx, int on);
 int rgbdslam_icp_line_rejections(rgbdslam_ctx *ctx, unsigned int *rejections);
 /* Debug: give-up time of the device-side waits in 10 ns ticks (default 5 000 000 = 50 ms; 0 = every waiter leaves at once). */
 int rgbdslam_debug_set_icp_timeout(rgbdslam_ctx *ctx, int ticks);
+/* Debug (no reference counterpart): this rank's tail waits `ticks` x 10 ns between publishing its line of the row-sharded
+ * exchange and its first poll -- the rank that falls behind in the tests of the double-buffered exchange slots. */
+int rgbdslam_debug_set_exchange_delay(rgbdslam_ctx *ctx, int ticks);
 
 /* Row-sharded form of the same loop (no reference counterpart: the reference is single-GPU;
  * SURVEY.md 8e / BASELINE.json configs[3]).  Each rank owns the 8x8-block rows

@@ -410,6 +410,11 @@ class RG:
         previous frame's kernels), 2 = Bump update on its own stream.  Before the first frame."""
         _hchk(self.lib.slamhost_rg_set_overlap_mode(self._h, int(mode)), "set_overlap_mode")
 
+    def set_stream_events(self, on):
+        """Overlap mode 1: order the load stream and the frame stream by events instead of stream value operations (needed
+        under `rocprofv3 --pmc`, which would hang the value waits).  Before the first frame."""
+        _hchk(self.lib.slamhost_rg_set_stream_events(self._h, int(on)), "set_stream_events")
+
     def history(self, first, count):
         """Poses of frames [first, first+count): rows of poseR(9, col-major) poset(3) tracked iterations level_iters 0."""
         import numpy as np

@@ -56,6 +56,8 @@ struct rgbdslam_ctx {
     unsigned int *xchg_peer[8];    // [xchg_rank] = this rank's own block; the others are IPC mappings of the peers' blocks
     int xchg_world, xchg_rank;
     unsigned int xchg_seq;         // advances once per exchanged iteration, in lockstep on every rank
+    int xchg_delay_ticks;          // rgbdslam_debug_set_exchange_delay (test hook)
+    unsigned long long *noalloc_zbuf;   // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc
     float *bil_lut; double bil_sigma_color;   // rgbdslam_bilateral_depth: colour-weight table (device) and the sigma it was built for
     // compat.hip: work buffers behind the reference-shaped Update_cu / Segment_cu / Overlap_cu (allocated on first use)
     uint64_t *claim_slab[RGBDSLAM_COMPAT_MAX_PLANES];   // one u64 claim word per Bump cell and plane
@@ -76,7 +78,7 @@ void prof_end(rgbdslam_ctx *ctx);
 bool prof_group_begin(rgbdslam_ctx *ctx, const char *kname);
 void prof_group_end(rgbdslam_ctx *ctx);
 // predict.hip: resolves the device address of the static z-buffer of rgbdslam_predict_raster_noalloc on `device`
-int raster_noalloc_setup(int device);
+int raster_noalloc_setup(int device, unsigned long long **out);
 #define KLAUNCH(ctx, kern, grid, block, ...)                                         \
     do {                                                                             \
         bool _prof = (ctx)->prof_name && prof_begin((ctx), #kern);                   \

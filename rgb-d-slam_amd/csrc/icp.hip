@@ -262,8 +262,14 @@ __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
 // its own block carry this iteration's sequence.  Line = four 32-byte sectors of 7 payload words + 1 tag word, tag =
 // seq ^ xor(payload words of the sector): a sector is accepted only when tag ^ xor(payload) == seq, so neither a stale nor
 // a torn sector (whatever granularity the fabric writes at) can pass for this iteration's.
+// The slots are DOUBLE-BUFFERED by the parity of the sequence: a rank that has gathered iteration s may publish s + 1 at once,
+// while a slower peer is still polling for the lines of s -- with one slot per rank that store would overwrite the line the
+// slow peer has not seen yet (with three or more ranks: C's line reaches A before B's does, A runs ahead), and the slow rank
+// would wait for the full timeout and lose the frame.  With two slots a rank overwrites its line of s only when it publishes
+// s + 2, i.e. after it has gathered every peer's line of s + 1, and a peer publishes s + 1 only after it has consumed s.
 #define ICP_XCHG_MAX_WORLD 8
-struct IcpXchg { unsigned int *peer[ICP_XCHG_MAX_WORLD]; int world, rank; unsigned int seq; };
+#define ICP_XCHG_SLOT_WORDS(rank, seq) (32u * ((unsigned)(rank) + ICP_XCHG_MAX_WORLD * ((seq) & 1u)))
+struct IcpXchg { unsigned int *peer[ICP_XCHG_MAX_WORLD]; int world, rank; unsigned int seq; int delay_ticks; };   // delay_ticks: test hook, see rgbdslam_debug_set_exchange_delay
 struct IcpIterArgs {
     int nx_lvl, nx_rows, nx_cols;                    // persistent loop: the level after this one (-1: none), its block grid
     IcpXchg xchg;                                    // world == 0: no exchange
@@ -650,9 +656,13 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             if ((lane & 7) == 7) word = a.xchg.seq ^ x;
             for (int p = 0; p < a.xchg.world; p++)
                 if (lane < 32)
-                    __hip_atomic_store(a.xchg.peer[p] + 32 * a.xchg.rank + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(a.xchg.peer[p] + ICP_XCHG_SLOT_WORDS(a.xchg.rank, a.xchg.seq) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.xchg.delay_ticks > 0) {            // test hook: this rank falls behind between its publication and its first poll
+                const long long t_d = wall_clock64();
+                while (wall_clock64() - t_d < (long long)a.xchg.delay_ticks) __builtin_amdgcn_s_sleep(32);
+            }
             // gather: lane reads word lane % 32 of lines 2i + lane / 32 of the own block
-            const unsigned int *mine = a.xchg.peer[a.xchg.rank];
+            const unsigned int *mine = a.xchg.peer[a.xchg.rank] + ICP_XCHG_SLOT_WORDS(0, a.xchg.seq);
             unsigned int v[ICP_XCHG_MAX_WORLD / 2];
             const long long t_poll = wall_clock64();
             bool gave_up = false;
@@ -1420,6 +1430,12 @@ extern "C" int rgbdslam_icp_line_rejections(rgbdslam_ctx *ctx, unsigned int *rej
 }
 // Debug: give-up time of every device-side wait of the ICP kernels in 10 ns ticks (default 5 000 000 = 50 ms); 0 makes every
 // waiter leave at once, which drives the give-up paths deterministically (tests).
+extern "C" int rgbdslam_debug_set_exchange_delay(rgbdslam_ctx *ctx, int ticks) {
+    if (!ctx || ticks < 0 || ticks > 1000000) return RGBDSLAM_E_ARG;         // at most 10 ms of the 100 MHz clock
+    ctx->xchg_delay_ticks = ticks;
+    return 0;
+}
+
 extern "C" int rgbdslam_debug_set_icp_timeout(rgbdslam_ctx *ctx, int ticks) {
     if (!ctx || ticks < 0) return RGBDSLAM_E_ARG;
     ctx->icp_timeout_ticks = ticks;
@@ -1683,7 +1699,7 @@ extern "C" int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int3
 }
 
 // ---- peer-mapped exchange of the 27 band sums (row-sharded ICP over several GPUs; no reference counterpart) ----------
-#define XCHG_BLOCK_BYTES (ICP_XCHG_MAX_WORLD * 128)
+#define XCHG_BLOCK_BYTES (2 * ICP_XCHG_MAX_WORLD * 128)   // two slots per rank (parity of the sequence)
 static_assert(sizeof(hipIpcMemHandle_t) <= RGBDSLAM_EXCHANGE_HANDLE_BYTES, "IPC handle size");
 
 extern "C" int rgbdslam_exchange_create(rgbdslam_ctx *ctx, int world, int rank, void *handle_out) {
@@ -1762,7 +1778,7 @@ extern "C" int rgbdslam_align_band_exchange(rgbdslam_ctx *ctx, const rgbdslam_ic
     for (int r = 0; r < ICP_XCHG_MAX_WORLD; r++) x.peer[r] = r < ctx->xchg_world ? ctx->xchg_peer[r] : nullptr;
     for (int r = 0; r < ctx->xchg_world; r++)
         if (!x.peer[r]) return RGBDSLAM_E_STATE;              // rgbdslam_exchange_connect has not run
-    x.world = ctx->xchg_world; x.rank = ctx->xchg_rank; x.seq = ++ctx->xchg_seq;
+    x.world = ctx->xchg_world; x.rank = ctx->xchg_rank; x.seq = ++ctx->xchg_seq; x.delay_ticks = ctx->xchg_delay_ticks;
     IcpState *st = ctx->icp_state;
     IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
     return launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, 1 << lvl, block_row_lo,

@@ -178,16 +178,19 @@ static __device__ __align__(256) unsigned long long scratch[RASTER_NOALLOC_MAX_P
 static std::mutex g_scratch_mutex;
 static unsigned long long *g_scratch_ptr[RASTER_NOALLOC_MAX_DEVICES];   // per device: that GPU's copy of `scratch`
 
-// Called from rgbdslam_create (the library's init call) with `device` current; idempotent.
-int raster_noalloc_setup(int device) {
-    if (device < 0 || device >= RASTER_NOALLOC_MAX_DEVICES) return RGBDSLAM_E_LIMIT;
+// Called from rgbdslam_create (the library's init call) with `device` current; idempotent.  *out = that device's copy of the
+// array; the context keeps it (ctx->noalloc_zbuf), so the entry point never reads the table.
+int raster_noalloc_setup(int device, unsigned long long **out) {
+    if (device < 0 || device >= RASTER_NOALLOC_MAX_DEVICES || !out) return RGBDSLAM_E_LIMIT;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (g_scratch_ptr[device]) return 0;
-    HIP_TRY(hipSetDevice(device));
-    void *ptr = nullptr;
-    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
-    if (!ptr) return -(int)hipErrorInvalidSymbol;
-    g_scratch_ptr[device] = (unsigned long long *)ptr;
+    if (!g_scratch_ptr[device]) {
+        HIP_TRY(hipSetDevice(device));
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return -(int)hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (unsigned long long *)ptr;
+    }
+    *out = g_scratch_ptr[device];
     return 0;
 }
 
@@ -196,9 +199,11 @@ extern "C" int rgbdslam_predict_raster_noalloc(rgbdslam_ctx *ctx, float *tex, co
     if (!ctx || !tex || !VMap || !RGBD || n < 2 || m < 2) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > (size_t)RASTER_NOALLOC_MAX_PIXELS) return RGBDSLAM_E_LIMIT;   // beyond the static z-buffer
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    if (ctx->device < 0 || ctx->device >= RASTER_NOALLOC_MAX_DEVICES) return RGBDSLAM_E_LIMIT;
-    unsigned long long *zbuf = g_scratch_ptr[ctx->device];   // resolved by rgbdslam_create on this device
+    unsigned long long *zbuf = ctx->noalloc_zbuf;            // this device's copy of `scratch`, resolved by rgbdslam_create
     if (!zbuf) return RGBDSLAM_E_STATE;
+    // the array lives on ctx->device: make that device current whatever the caller's is (the NULL stream and the kernel
+    // launches follow the current device).  hipSetDevice allocates nothing and is legal under stream capture.
+    HIP_TRY(hipSetDevice(ctx->device));
     // the array keeps the last call's contents (an aborted call could leave claimed words): the words this call
     // uses start at "empty" whatever ran before
     HIP_TRY(hipMemsetAsync(zbuf, 0xFF, sizeof(unsigned long long) * (size_t)n * m, ctx->stream));

@@ -210,17 +210,31 @@ void OffLineFrame::AttachLoadStream(hipStream_t load_stream) {
         _depth_dev_test[1].alloc(P); _color_dev_test[1].alloc(3 * P);
     }
     if (_gradients) EnableGradients(true);
-    for (int k = 0; k < 2; k++) {
-        if (_use_events) {
-            if (!_ready[k]) hip_check(hipEventCreateWithFlags(&_ready[k], hipEventDisableTiming), "hipEventCreate");
-            if (!_free[k]) hip_check(hipEventCreateWithFlags(&_free[k], hipEventDisableTiming), "hipEventCreate");
-        } else if (!_sig_ready[k]) {                           // signal memory comes in 8-byte allocations
-            hip_check(hipExtMallocWithFlags((void **)&_sig_ready[k], 8, hipMallocSignalMemory), "signal memory");
-            hip_check(hipExtMallocWithFlags((void **)&_sig_free[k], 8, hipMallocSignalMemory), "signal memory");
+    // stream value operations need signal memory: when the allocation is refused, fall back to events (2.5x the cost per
+    // hand-over, the same ordering) instead of failing
+    if (!_use_events) {
+        for (int k = 0; k < 2 && !_use_events; k++) {
+            if (_sig_ready[k]) continue;
+            if (hipExtMallocWithFlags((void **)&_sig_ready[k], 8, hipMallocSignalMemory) != hipSuccess ||     // 8-byte allocations
+                hipExtMallocWithFlags((void **)&_sig_free[k], 8, hipMallocSignalMemory) != hipSuccess) {
+                (void)hipGetLastError();
+                _use_events = true;
+                break;
+            }
             hip_check(hipMemset(_sig_ready[k], 0, 8), "hipMemset");
             hip_check(hipMemset(_sig_free[k], 0, 8), "hipMemset");
         }
+        if (_use_events)
+            for (int k = 0; k < 2; k++) {
+                if (_sig_ready[k]) { (void)hipFree(_sig_ready[k]); _sig_ready[k] = nullptr; }
+                if (_sig_free[k]) { (void)hipFree(_sig_free[k]); _sig_free[k] = nullptr; }
+            }
     }
+    if (_use_events)
+        for (int k = 0; k < 2; k++) {
+            if (!_ready[k]) hip_check(hipEventCreateWithFlags(&_ready[k], hipEventDisableTiming), "hipEventCreate");
+            if (!_free[k]) hip_check(hipEventCreateWithFlags(&_free[k], hipEventDisableTiming), "hipEventCreate");
+        }
 }
 
 void OffLineFrame::wait_ready(hipStream_t consumer) {
@@ -1417,6 +1431,15 @@ int slamhost_rg_set_overlap_mode(void *rg, int mode) {
     if (((RG *)rg)->_count != 1) return RGBDSLAM_E_STATE;
     ((RG *)rg)->overlap = mode != 0;
     ((RG *)rg)->set_overlap_mode(mode);
+    return 0;
+}
+// 1: the load stream and the frame's stream are ordered by events instead of stream value operations (2.5x the cost per
+// hand-over; needed under counter-collecting profilers, which never let the producer queue run while the consumer waits on a
+// value).  Before the first frame only.  Same switch as RGBDSLAM_STREAM_EVENTS=1.
+int slamhost_rg_set_stream_events(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    if (((RG *)rg)->_count != 1) return RGBDSLAM_E_STATE;
+    FACADE_TRY(((RG *)rg)->_frame->set_stream_events(on != 0));
     return 0;
 }
 int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {

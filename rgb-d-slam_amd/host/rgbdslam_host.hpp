@@ -132,6 +132,8 @@ public:
     // Overlap: loads go to `load_stream` and alternate between the two buffer sets.  wait_ready(consumer) = the current
     // set is preprocessed (the consumer stream waits on it); release(consumer) = the consumer's work enqueued
     // so far is the last that reads the current set (the load that next reuses the set waits on it).
+    // Ordering primitive: stream value operations by default, events on request or when signal memory is refused; see
+    // set_stream_events below for the profiler hang the default can run into.
     void AttachLoadStream(hipStream_t load_stream);
     hipStream_t load_stream() const { return _load_stream; }
     void wait_ready(hipStream_t consumer);                         // the consumer stream waits for the current set's maps
@@ -151,8 +153,18 @@ private:
     // The two streams are ordered by stream VALUE operations on two words of signal memory per buffer set (ready: written
     // by the load stream, awaited by the consumer; free: the reverse), sequence numbers counting up: measured on this
     // system (tools/microbench/stream_sync.hip) an event record + wait costs ~16 us per hand-over, a value write + wait ~6.
-    // RGBDSLAM_STREAM_EVENTS=1 selects events.
+    // RGBDSLAM_STREAM_EVENTS=1, RG::set_stream_events(true) / slamhost_rg_set_stream_events select events, and so does a refused
+    // signal-memory allocation.  CAUTION: a profiler that collects hardware counters (rocprofv3 --pmc) serialises the
+    // queues; the producer stream then never runs while the consumer sits in hipStreamWaitValue32, and the process hangs --
+    // profile load-stream applications with events.
     bool _use_events = getenv("RGBDSLAM_STREAM_EVENTS") != nullptr;
+public:
+    void set_stream_events(bool on) {
+        if (_load_stream) throw Error("set_stream_events: the load stream is already attached", RGBDSLAM_E_STATE);
+        _use_events = on;
+    }
+    bool stream_events() const { return _use_events; }
+private:
     hipEvent_t _ready[2] = {nullptr, nullptr}, _free[2] = {nullptr, nullptr};
     uint32_t *_sig_ready[2] = {nullptr, nullptr}, *_sig_free[2] = {nullptr, nullptr};
     uint32_t _seq_ready[2] = {0, 0}, _seq_free[2] = {0, 0};

@@ -4,7 +4,7 @@
 * 2 ranks rehearsed on one GPU (gloo for the process group, RGBDSLAM_BENCH_DEVICE=0): the peer exchange maps each other's
   block over HIP IPC and both ranks must hold identical poses (bench.py checks that itself and refuses otherwise); the
   plane-partitioned model after N steps must carry the same checksum as the single-rank run.
-Never more than 2 ranks on the card."""
+Never more than 3 ranks on the card."""
 import importlib
 import json
 import os
@@ -29,8 +29,9 @@ def _free_port():
     return p
 
 
-def _bench(args, world=1, timeout=170):
+def _bench(args, world=1, timeout=170, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     if world > 1:
         env.update(RGBDSLAM_BENCH_BACKEND="gloo", RGBDSLAM_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -89,6 +90,20 @@ def test_rows_mode_two_ranks_on_one_card_peer_and_allgather():
     # against the unsharded run only the float32 summation order differs: BASELINE's 1e-5 rad / 1e-5 m bar
     assert np.allclose(outs["peer"]["config"]["pose"], one["config"]["pose"], atol=1e-5, rtol=0)
     assert "peer" in outs["peer"]["config"]["workload"]
+
+
+def test_rows_mode_three_ranks_one_of_them_delayed():
+    """The peer exchange with a rank that falls behind: rank 2 sleeps 300 us between publishing its line and its
+    first poll, in every iteration.  Ranks 0 and 1 meanwhile gather iteration s and publish s + 1.  With ONE slot per rank that
+    store overwrote the line of s the slow rank had not read yet (it then waited 50 ms in vain, lost the frame and the ranks'
+    poses diverged); the slots are double-buffered by the parity of the sequence, so the slow rank still finds s.
+    Three ranks on one card, poses identical on all ranks (bench.py refuses otherwise) and identical to the all-gather form."""
+    size = ["--mode", "rows", "--rows", "240", "--cols", "320", "--steps", "3", "--warmup", "1"]
+    ag = _bench(size + ["--exchange", "allgather"], world=3)
+    delayed = _bench(size + ["--exchange", "peer"], world=3, extra_env={"RGBDSLAM_BENCH_XCHG_DELAY": "2:30000"})
+    assert delayed["n_gpus"] == 3 and delayed["config"]["pose"] == ag["config"]["pose"]
+    assert delayed["config"]["icp_iterations_per_level"] == ag["config"]["icp_iterations_per_level"]
+    assert delayed["ms_per_step"] > 12 * 0.3 * 0.9, "the delay was applied (12 iterations x 300 us)"
 
 
 def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():

@@ -62,3 +62,25 @@ def test_predict_raster_noalloc_matches_workspace_form(pkg, synth, orc):
         assert "code 3" in str(e.value)                          # RGBDSLAM_E_LIMIT
     finally:
         ctx.close()
+
+
+def test_predict_raster_noalloc_on_a_stream_of_its_own(pkg, synth, orc):
+    """The context's stream is not the NULL stream: the memset of the static z-buffer and both kernels must follow the
+    context's stream and device (the entry point makes ctx->device current itself)."""
+    stream = torch.cuda.Stream()
+    n, m = 120, 160
+    calib, v, rgbd = _scene(synth, orc, n, m, seed=5)
+    g_v = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    g_rgbd = torch.from_numpy(np.ascontiguousarray(rgbd)).cuda()
+    tex = torch.full((n, m, 4), -7.0, device="cuda")
+    torch.cuda.synchronize()
+    ctx = pkg.Context(0, stream.cuda_stream)
+    try:
+        ctx.set_calibration_matrix(calib)
+        for _ in range(2):
+            ctx.predict_raster_noalloc(tex, g_v, g_rgbd, None, n, m)
+        ctx.synchronize()
+        want, _ = orc.raster(v, rgbd, calib)
+        assert np.array_equal(tex.cpu().numpy().view(np.uint32), np.asarray(want, np.float32).view(np.uint32))
+    finally:
+        ctx.close()
