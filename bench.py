@@ -348,6 +348,29 @@ def run_planes(args, env):
                 acc["predict_draw_merge_resolve"] += marks[q + 3][1].elapsed_time(marks[q + 4][1])
             phases = {k_: round(v / reps * 1e3, 1) for k_, v in acc.items()}
             phases["unit"] = "us per step on rank 0 (event pairs on its stream, second pass)"
+        # the other kernels of the step, one profiled pass each (the library's hook follows one kernel name at a time)
+        planes_kernels = []
+        ev0 = C.c_double()
+        lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev0))
+        usable = int((shard.mask > 10).sum()) + int((shard.mask == 1).sum())
+        owned_cells = (shard.hi - shard.lo) * N * N
+        extra = [("k_update<true>", (12 + 16 + 1 + 2 + 10) * n * m, "Graph::Update apply pass, u16 labels: 41 B per frame pixel")]
+        if args.planes_predict:
+            covered = int((shard.pred_v[..., 2] != 0).sum()) if getattr(shard, "pred_v", None) is not None else 0
+            extra += [("k_planes_draw", owned_cells + 6 * usable + 8 * covered,
+                       "1 B mask per owned cell (every byte has to be looked at) + 6 B Bump words per usable cell + 8 B z-word per drawn pixel"),
+                      ("k_planes_resolve", (8 + 3 * 10 + 12 + 16) * n * m, "z-word + three 10-byte cells read, VMap + RGBD written, per pixel")]
+        if rank == 0:
+            extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
+        for kname, nbytes, what in extra:
+            t_ms, cnt = _profile(lib, ctx._h, kname, lambda: [step() for _ in range(min(reps, 20))])
+            stream.synchronize()
+            if cnt == 0:
+                continue
+            us = max(1e-3, (t_ms / cnt - ev0.value) * 1e3)
+            gbs = nbytes / (us * 1e-6) / 1e9
+            planes_kernels.append({"kernel": kname, "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(nbytes),
+                                   "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": what})
         # "a checksum of checksums": the model after all steps, independent of how the planes were partitioned
         chk = torch.tensor([int(shard.bump.to(torch.int64).sum()) + 3 * int(shard.rgb.to(torch.int64).sum()) + 7 * int(shard.mask.to(torch.int64).sum()),
                             int((shard.mask > 10).sum())], dtype=torch.int64, device=env["coll_dev"])
@@ -382,7 +405,7 @@ def run_planes(args, env):
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                             "algorithmic_bytes_per_launch": 54 * cells, "avg_launch_us": round(avg_ms * 1e3, 2),
                             "note": "rank 0's share: 54 B per owned Bump cell per launch"},
-               "phases": phases, "cpu_baseline": None,
+               "phases": phases, "planes_kernels": planes_kernels, "cpu_baseline": None,
                "model_checksum": int(chk[0].item()), "cells_fused": int(chk[1].item()),
                "prediction_checksum": int(chk[2].item()) if args.planes_predict else None,
                "predicted_coverage": round(int(chk[3].item()) / float(n * m), 4) if args.planes_predict else None}

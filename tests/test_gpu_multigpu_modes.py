@@ -103,7 +103,8 @@ def test_rows_mode_three_ranks_one_of_them_delayed():
     delayed = _bench(size + ["--exchange", "peer"], world=3, extra_env={"RGBDSLAM_BENCH_XCHG_DELAY": "2:30000"})
     assert delayed["n_gpus"] == 3 and delayed["config"]["pose"] == ag["config"]["pose"]
     assert delayed["config"]["icp_iterations_per_level"] == ag["config"]["icp_iterations_per_level"]
-    assert delayed["ms_per_step"] > 12 * 0.3 * 0.9, "the delay was applied (12 iterations x 300 us)"
+    iters = sum(delayed["config"]["icp_iterations_per_level"])
+    assert iters >= 6 and delayed["ms_per_step"] > iters * 0.3 * 0.9, "the delay was applied (300 us in every executed iteration)"
 
 
 def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():

@@ -135,3 +135,61 @@ def test_256_planes_eight_way_partition_equals_single_launch(ctx, orc, pair, syn
                         size=(N, N))
     same(host(single).view(np.uint64), z_ref)
     assert max(touched) == 255                                   # ids of the last plane fit the 32-bit triangle id
+
+
+@pytest.mark.parametrize("N,M,offset", [(150, 203, 0), (77, 208, 0), (130, 256, 1), (9, 66, 0), (64, 1040, 0)])
+def test_planes_draw_ragged_sizes_and_unaligned_slabs(ctx, orc, synth, N, M, offset):
+    """The mask scan of k_planes_draw reads 16-byte pieces of rows where the rows are 16-byte aligned and single bytes where
+    they are not (M_prim % 16 != 0, or a slab that starts at an odd address); tiles are grouped four to a workgroup, so
+    widths that leave 1-3 tiles in the last group, a last tile of a few columns and Bump images narrower than one group are
+    all drawn.  Sparse masks (most tiles empty, some holding a single usable cell, the locked value 1 counted as usable);
+    z-keys bit-exact against the oracle for two planes."""
+    n, m = 240, 320
+    calib = synth.calib_for(n, m)
+    ctx.set_calibration_matrix(calib)
+    try:
+        rng = np.random.default_rng(N * 1000 + M)
+        bumps, rgbs, masks, params = [], [], [], []
+        for k in range(2):
+            b = np.empty((N, M, 3), np.uint16)
+            b[..., :2] = rng.integers(0, 60000, (N, M, 2))
+            b[..., 2] = 30000 + rng.integers(-20, 20, (N, M))
+            mk = np.full((N, M), 10, np.uint8)
+            for _ in range(6):                                   # a few filled patches, a few lone cells
+                i, j = int(rng.integers(0, N)), int(rng.integers(0, M))
+                mk[i:i + int(rng.integers(2, 24)), j:j + int(rng.integers(2, 90))] = rng.integers(11, 40)
+            mk[rng.integers(0, N, 5), rng.integers(0, M, 5)] = 12
+            mk[rng.integers(0, N, 3), rng.integers(0, M, 3)] = 1
+            mk[N - 1, M - 1] = 30; mk[N - 2:, M - 3:] = 30       # the ragged corner
+            bumps.append(b); masks.append(mk); rgbs.append(rng.integers(0, 255, (N, M, 3)).astype(np.uint8))
+            # fronto-parallel patch 2 m (k = 0) / 2.3 m (k = 1) in front of the camera, 4 mm cells
+            params.append(np.array([0, 0, 1, -2.0 - 0.3 * k, 500, 500, -0.25 - 0.1 * k, -0.3, 1, 0, 0, 0, 1, 0], np.float32))
+
+        def slab(a):                                             # device copy that starts `offset` bytes into its allocation
+            raw = torch.empty(a.nbytes + 16, dtype=torch.uint8, device="cuda")
+            view = raw[offset:offset + a.nbytes]
+            view.copy_(torch.from_numpy(a.reshape(-1).view(np.uint8)).cuda())
+            return raw, view.data_ptr()
+        keep = []
+        ptrs = {"b": [], "c": [], "m": []}
+        for k in range(2):
+            for key, arr, off_ok in (("b", bumps[k], False), ("c", rgbs[k], True), ("m", masks[k], True)):
+                if off_ok:
+                    raw, p = slab(arr)
+                else:                                            # u16 words stay 2-byte aligned
+                    raw = torch.from_numpy(arr).cuda(); p = raw.data_ptr()
+                keep.append(raw); ptrs[key].append(p)
+        g_par = dev(np.stack(params))
+        tab = lambda lst: torch.tensor(lst, dtype=torch.int64, device="cuda")
+        t_b, t_c, t_m = tab(ptrs["b"]), tab(ptrs["c"]), tab(ptrs["m"])
+        t_p = tab([g_par[k].data_ptr() for k in range(2)])
+        P = pose16(np.eye(3), np.zeros(3))
+        zbuf = torch.empty(n, m, dtype=torch.int64, device="cuda")
+        ctx.raster_clear(zbuf, n, m)
+        ctx.planes_draw(zbuf, t_b, t_c, t_m, t_p, 0, 2, P, N, M, n, m)
+        z_ref = np.full((n, m), 0xFFFFFFFFFFFFFFFF, np.uint64)
+        orc.planes_draw(z_ref, bumps, rgbs, masks, params, 0, 2, P, calib, n, m, min_conf=1)
+        same(host(zbuf).view(np.uint64), z_ref)
+        assert (z_ref != 0xFFFFFFFFFFFFFFFF).sum() > 50
+    finally:
+        ctx.set_calibration_matrix(synth.TUM_CALIB)
