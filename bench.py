@@ -270,7 +270,7 @@ def run_planes(args, env):
                 except RuntimeError:
                     pass
         order, k, d = [], 0, 1
-        for _ in range(2 * (args.warmup + args.steps) + 2):
+        for _ in range(2 * (args.warmup + args.steps) + 2 + 5 * 20):    # timed pass, phase pass, one short pass per profiled kernel
             order.append(k)
             if k + d < 0 or k + d >= POOL_FRAMES:
                 d = -d
@@ -354,14 +354,16 @@ def run_planes(args, env):
         lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev0))
         usable = int((shard.mask > 10).sum()) + int((shard.mask == 1).sum())
         owned_cells = (shard.hi - shard.lo) * N * N
+        occupied_tiles = int((shard.mask.view(-1, N // 8, 8, N // 64, 64) > 10).any(dim=4).any(dim=2).sum()) if shard.hi > shard.lo else 0
         extra = [("k_update<true>", (12 + 16 + 1 + 2 + 10) * n * m, "Graph::Update apply pass, u16 labels: 41 B per frame pixel")]
         if args.planes_predict:
             covered = int((shard.pred_v[..., 2] != 0).sum()) if getattr(shard, "pred_v", None) is not None else 0
-            extra += [("k_planes_draw", owned_cells + 6 * usable + 8 * covered,
-                       "1 B mask per owned cell (every byte has to be looked at) + 6 B Bump words per usable cell + 8 B z-word per drawn pixel"),
+            extra += [("k_planes_scan", owned_cells, "1 B mask per owned cell: every byte has to be looked at, no occupancy is kept between calls"),
+                      ("k_planes_draw", 7 * 585 * occupied_tiles + 8 * covered,
+                       "7 B (mask + Bump words) per cell of the 9 x 65 cells of every occupied tile + 8 B z-word per drawn pixel"),
                       ("k_planes_resolve", (8 + 3 * 10 + 12 + 16) * n * m, "z-word + three 10-byte cells read, VMap + RGBD written, per pixel")]
-        if rank == 0:
-            extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
+        # (every rank walks the same list: each pass runs steps, and a step holds collectives; the label kernel only runs on rank 0)
+        extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
         for kname, nbytes, what in extra:
             t_ms, cnt = _profile(lib, ctx._h, kname, lambda: [step() for _ in range(min(reps, 20))])
             stream.synchronize()

@@ -57,6 +57,8 @@ struct rgbdslam_ctx {
     int xchg_world, xchg_rank;
     unsigned int xchg_seq;         // advances once per exchanged iteration, in lockstep on every rank
     int xchg_delay_ticks;          // rgbdslam_debug_set_exchange_delay (test hook)
+    // rgbdslam_planes_draw: [0] / [32] the two tile counters (call parity), from word 64 one stamp word per tile, then the queue
+    uint32_t *pd_scratch; size_t pd_cap; uint32_t pd_stamp;
     unsigned long long *noalloc_zbuf;   // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc
     float *bil_lut; double bil_sigma_color;   // rgbdslam_bilateral_depth: colour-weight table (device) and the sigma it was built for
     // compat.hip: work buffers behind the reference-shaped Update_cu / Segment_cu / Overlap_cu (allocated on first use)

@@ -29,7 +29,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_launches = 0; c->prof_in_group = false;
     // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc (predict.hip), resolved here so that
     // the entry point itself never has to
-    c->noalloc_zbuf = nullptr;
+    c->noalloc_zbuf = nullptr; c->pd_scratch = nullptr; c->pd_cap = 0; c->pd_stamp = 0;
     int rc = raster_noalloc_setup(device, &c->noalloc_zbuf);
     if (rc) { delete c; return rc; }
     *out = c;
@@ -41,6 +41,7 @@ extern "C" int rgbdslam_destroy(rgbdslam_ctx *ctx) {
     rgbdslam_free_buffers(ctx);
     compat_release(ctx);
     if (ctx->bil_lut) { (void)hipFree(ctx->bil_lut); ctx->bil_lut = nullptr; }
+    if (ctx->pd_scratch) { (void)hipFree(ctx->pd_scratch); ctx->pd_scratch = nullptr; }
     rgbdslam_exchange_destroy(ctx);
     rgbdslam_profile_kernel(ctx, nullptr);
     for (int k = 0; k < 2 * ctx->prof_cap; k++) (void)hipEventDestroy(ctx->prof_ev[k]);

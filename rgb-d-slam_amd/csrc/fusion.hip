@@ -291,7 +291,6 @@ extern "C" int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *
 // test and the two in-plane coordinates are evaluated once per run (same operands, same operations: the same bits the
 // per-plane evaluation gave), a run no lane of the wave belongs to is jumped over, and inside a run only the cell
 // containment is tested per member.  The first match in plane order is unchanged (tests vs orc.label_planes_l16).
-// 85 -> 16 us for 256 planes at 640 x 480.
 #define LBL_CHUNK (TILE_W * TILE_H)
 __global__ __launch_bounds__(TILE_W * TILE_H)
 void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *__restrict__ VMap, const float *__restrict__ NMap,
@@ -359,15 +358,43 @@ void k_label_planes_l16(uint16_t *__restrict__ Label16, const float *__restrict_
                 // update_cell's in-plane coordinates (device_fns.hpp), the part that does not depend on the shift
                 const float a0 = (p.x * Q[8] + p.y * Q[9]) + p.z * Q[10];
                 const float b0 = (p.x * Q[11] + p.y * Q[12]) + p.z * Q[13];
-                for (int kk = k; kk < kend && __ballot(fits); kk++) {
-                    if (!fits) continue;
-                    const float a = (float)((double)((a0 - sq[kk][6]) * Q[4]) / 2.0);
-                    const float b = (float)((double)((b0 - sq[kk][7]) * Q[5]) / 2.0);
-                    const int ii = f2i_rd(a), jj = f2i_rd(b);
-                    if (ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0) continue;
-                    res = (uint16_t)(base + kk + 1);
-                    open = false;
-                    fits = false;
+                // Which members of the run can hold a cell of this wave at all?  The wave's 64 pixels are neighbours in a
+                // row: their (a0, b0) span a small box.  A member's image spans [shift, shift + 2 N / scale) in each
+                // coordinate; 64 members at a time, one per lane, are tested against the box with a generous margin (the
+                // exact test below decides; a member skipped here cannot pass it for any lane), and only the candidates --
+                // one or two of the ~85 patches that tile a wall -- are walked in plane order.
+                float amin = fits ? a0 : __builtin_inff(), amax = fits ? a0 : -__builtin_inff();
+                float bmin = fits ? b0 : __builtin_inff(), bmax = fits ? b0 : -__builtin_inff();
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    amin = fminf(amin, __shfl_xor(amin, o)); amax = fmaxf(amax, __shfl_xor(amax, o));
+                    bmin = fminf(bmin, __shfl_xor(bmin, o)); bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+                }
+                const float ext0 = 2.0f * (float)N_prim / Q[4], ext1 = 2.0f * (float)M_prim / Q[5];
+                const int lane = tid & 63;
+                for (int kb = k; kb < kend && __ballot(fits); kb += 64) {
+                    const int mk = min(kb + lane, kend - 1);
+                    const float s6 = sq[mk][6], s7 = sq[mk][7];
+                    const float mg0 = 1e-5f * (((__builtin_fabsf(s6) + __builtin_fabsf(ext0)) + __builtin_fabsf(amin)) + __builtin_fabsf(amax)) + 1e-7f;
+                    const float mg1 = 1e-5f * (((__builtin_fabsf(s7) + __builtin_fabsf(ext1)) + __builtin_fabsf(bmin)) + __builtin_fabsf(bmax)) + 1e-7f;
+                    // written so that a NaN anywhere keeps the member (it is then decided by the exact test)
+                    // (a negative scale mirrors the extent; a zero scale puts every pixel into cell 0: then nothing is skipped)
+                    const float lo0 = fminf(s6, s6 + ext0), hi0 = fmaxf(s6, s6 + ext0), lo1 = fminf(s7, s7 + ext1), hi1 = fmaxf(s7, s7 + ext1);
+                    const bool bounded = __builtin_fabsf(ext0) < 3e38f && __builtin_fabsf(ext1) < 3e38f;
+                    const bool out = bounded && (amax < lo0 - mg0 || amin > hi0 + mg0 || bmax < lo1 - mg1 || bmin > hi1 + mg1);
+                    unsigned long long cand = __ballot(kb + lane < kend && !out);
+                    while (cand != 0ull && __ballot(fits)) {
+                        const int kk = kb + __builtin_ctzll(cand);
+                        cand &= cand - 1ull;
+                        if (!fits) continue;
+                        const float a = (float)((double)((a0 - sq[kk][6]) * Q[4]) / 2.0);
+                        const float b = (float)((double)((b0 - sq[kk][7]) * Q[5]) / 2.0);
+                        const int ii = f2i_rd(a), jj = f2i_rd(b);
+                        if (ii > N_prim - 1 || jj > M_prim - 1 || ii < 0 || jj < 0) continue;
+                        res = (uint16_t)(base + kk + 1);
+                        open = false;
+                        fits = false;
+                    }
                 }
             }
             k = kend;

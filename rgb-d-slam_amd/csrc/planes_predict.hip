@@ -10,82 +10,101 @@
 #include "device_fns.hpp"
 
 #define PD_ROWS 8                      // quad rows per tile (tile: PD_ROWS+1 x 65 cells in LDS)
-#define PD_TPW 4                       // tiles (of 64 quads, side by side) per workgroup: one wave scans the masks of one
+#define PD_DRAW_WGS 2048               // workgroups of the draw launch (each walks the queue with that stride)
 struct PlaneTabs {
     const uint16_t *const *Bump; const uint8_t *const *RGB; const uint8_t *const *Mask; const float *const *Param;
 };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool pd_corner_rejected(uint8_t mk, int min_conf) { return mk != 1 && (int)mk - 10 < min_conf; }
-// any of the four mask bytes of w a usable corner?  (!pd_corner_rejected: mk == 1 or mk >= min_conf + 10 = thr)
-__device__ __forceinline__ int pd_any_accepted4(uint32_t w, int thr) {
-    int a = 0;
+// which of the four mask bytes of w are usable corners?  (!pd_corner_rejected: mk == 1 or mk >= min_conf + 10 = thr); bit k = byte k
+__device__ __forceinline__ uint32_t pd_accepted4(uint32_t w, int thr) {
+    uint32_t a = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int b = (int)((w >> (8 * k)) & 255u);
-        a |= (int)(b == 1) | (int)(b >= thr);
+        a |= (uint32_t)((b == 1) | (b >= thr)) << k;
     }
     return a;
 }
 
-// One workgroup = PD_TPW tiles of 64 x PD_ROWS quads of one plane.
-// Phase 1, the part that decides the kernel's time (99.5 % of the tiles of a 256-plane model are empty in a given view; every
-// mask byte has to be looked at, 67 MB for 256 planes x 512^2): wave w reads the (PD_ROWS+1) x 65 mask bytes of tile w as ONE
-// load per lane -- 36 lanes a 16-byte piece of a row each, 9 lanes the 65th byte of a row -- and a ballot says whether the tile
-// holds a usable corner at all.  A workgroup whose four tiles are empty leaves after one load, one ballot and one barrier,
-// before it has touched the plane's parameters or any LDS tile.  (Round 2: one workgroup per tile, 585 byte loads through a
-// division by 65, two barriers: 226 us for this model.)  Rows that are not 16-byte aligned (M_prim % 16 != 0 or an unaligned
-// slab) take byte loads.
-// Phase 2, per non-empty tile, all four waves together: the (PD_ROWS+1) x 65 cells are decoded ONCE into LDS (world-space
-// vertex, camera-space projection, mask), then one lane per quad trims and draws.
+// Two launches.  Round 2 drew with one workgroup per 64 x 8-quad tile: 131 072 workgroups for 256 planes x 512^2, each reading
+// its 9 x 65 mask bytes one byte per lane through a division by 65 and meeting at two barriers only to find -- 99.5 % of
+// the time -- that its tile is empty: 226 us.  Every mask byte has to be looked at (67 MB: no occupancy is kept between
+// calls), so the first launch does just that, shaped for bandwidth, and leaves a queue of the occupied tiles; the second
+// draws the queue, one tile per workgroup, however the occupied tiles are spread over the planes (in the tiled scene they
+// sit in a dozen planes at the END of the grid: drawn where they were found, they ran after everything else, four to a
+// workgroup one after the other).
+//
+// k_planes_scan: one thread = one 16-column piece of one band of PD_ROWS quad rows (PD_ROWS + 1 cell rows): nine 16-byte
+// loads in flight per lane (9 KB per wave; one load per lane kept only 3.6 MB in flight on the whole chip: 1.65 TB/s).  A
+// piece that holds a usable corner marks its tile, and -- through its first column, the 65th of the tile to its left --
+// that one; the first to mark a tile (atomicMax of the call's stamp on the tile's word: no clearing between calls)
+// appends it to the queue.  Rows that are not 16-byte aligned (M_prim % 16 != 0, or a slab at an odd address) are read
+// bytewise.
+__global__ __launch_bounds__(256)
+void k_planes_scan(PlaneTabs T, int plane_lo, int N, int M, int min_conf, int pieces, int bands, int tiles_x,
+                   uint32_t *__restrict__ flags, uint32_t *__restrict__ queue, uint32_t *__restrict__ count, uint32_t stamp) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= pieces * bands) return;
+    const int band = g / pieces, pc = g % pieces;
+    const int plane = plane_lo + blockIdx.y;
+    const GLOBAL_AS uint8_t *__restrict__ Maskb = (const GLOBAL_AS uint8_t *)T.Mask[plane];
+    const int thr = min_conf + 10;
+    const int i0 = band * PD_ROWS, j0 = 16 * pc;
+    uint32_t acc = 0;                                // bit c: column j0 + c holds a usable corner in one of the band's rows
+    if (((((uintptr_t)Maskb) | (uintptr_t)(unsigned)M) & (uintptr_t)15) == 0) {
+        u32x4 w[PD_ROWS + 1];
+#pragma unroll
+        for (int r = 0; r <= PD_ROWS; r++) {         // all loads first; rows below the image repeat the last one
+            const int i = min(i0 + r, N - 1);
+            w[r] = *(const GLOBAL_AS u32x4 *)(Maskb + (size_t)i * M + j0);
+        }
+#pragma unroll
+        for (int r = 0; r <= PD_ROWS; r++)
+            acc |= pd_accepted4(w[r].x, thr) | pd_accepted4(w[r].y, thr) << 4 | pd_accepted4(w[r].z, thr) << 8 | pd_accepted4(w[r].w, thr) << 12;
+    } else {
+        for (int r = 0; r <= PD_ROWS; r++) {
+            const int i = i0 + r;
+            if (i >= N) break;
+            for (int cc = 0; cc < 16 && j0 + cc < M; cc++)
+                acc |= (uint32_t)!pd_corner_rejected(Maskb[(size_t)i * M + j0 + cc], min_conf) << cc;
+        }
+    }
+    if (!acc) return;
+    const uint32_t tiles_per_plane = (uint32_t)tiles_x * (uint32_t)bands;
+    const uint32_t tbase = (uint32_t)blockIdx.y * tiles_per_plane + (uint32_t)band * (uint32_t)tiles_x;
+    const int tx = pc >> 2;
+    if (tx < tiles_x) {                              // (the last column of an image of 64 k + 1 columns belongs to no tile of its own)
+        if (atomicMax(&flags[tbase + tx], stamp) < stamp) queue[atomicAdd(count, 1u)] = tbase + tx;
+    }
+    if ((acc & 1u) && (pc & 3) == 0 && tx > 0) {     // column 64 of the tile to the left
+        if (atomicMax(&flags[tbase + tx - 1], stamp) < stamp) queue[atomicAdd(count, 1u)] = tbase + tx - 1;
+    }
+}
+
+// k_planes_draw: one queued tile at a time per workgroup.  The (PD_ROWS+1) x 65 cells of the tile are decoded ONCE into LDS
+// (world-space vertex, camera-space projection, mask), then one lane per quad trims and draws.  Block 0 clears the OTHER
+// call parity's counter for the next call's scan.
 __global__ __launch_bounds__(256)
 void k_planes_draw(unsigned long long *__restrict__ zbuf, PlaneTabs T, int plane_lo, PoseV P, CalibV c, int N, int M, int min_conf,
-                   float thresh, float znear, float zfar, int n, int m) {
+                   float thresh, float znear, float zfar, int n, int m, int bands, int tiles_x, const uint32_t *__restrict__ queue,
+                   const uint32_t *__restrict__ count, uint32_t *__restrict__ next_count) {
     __shared__ float sw[PD_ROWS + 1][65][3];       // world-space vertices (trim test, Primitive.cu:112-133)
     __shared__ RasVert sp[PD_ROWS + 1][65];        // projected camera-space vertices
     __shared__ uint8_t sm[PD_ROWS + 1][65];
-    __shared__ int occ[PD_TPW];
-    const int plane = plane_lo + blockIdx.z;
-    const int i0 = blockIdx.y * PD_ROWS;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const GLOBAL_AS uint8_t *__restrict__ Maskb = (const GLOBAL_AS uint8_t *)T.Mask[plane];
-    {
-        const int thr = min_conf + 10;
-        const int j0 = (blockIdx.x * PD_TPW + wave) * 64;
-        bool acc = false;
-        if (j0 <= M - 2) {                           // the tile exists
-            if (((((uintptr_t)Maskb) | (uintptr_t)(unsigned)M) & (uintptr_t)15) == 0) {
-                if (lane < 4 * (PD_ROWS + 1)) {
-                    const int i = i0 + (lane >> 2), j = j0 + 16 * (lane & 3);
-                    if (i < N && j < M) {            // M % 16 == 0: the 16 bytes lie inside the row
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 w = *(const GLOBAL_AS u32x4 *)(Maskb + (size_t)i * M + j);
-                        acc = (pd_any_accepted4(w.x, thr) | pd_any_accepted4(w.y, thr) | pd_any_accepted4(w.z, thr) | pd_any_accepted4(w.w, thr)) != 0;
-                    }
-                } else if (lane < 5 * (PD_ROWS + 1)) {
-                    const int i = i0 + lane - 4 * (PD_ROWS + 1), j = j0 + 64;
-                    if (i < N && j < M) acc = !pd_corner_rejected(Maskb[(size_t)i * M + j], min_conf);
-                }
-            } else {
-                for (int e = lane; e < (PD_ROWS + 1) * 65; e += 64) {
-                    const int i = i0 + e / 65, j = j0 + e % 65;
-                    if (i < N && j < M) acc |= !pd_corner_rejected(Maskb[(size_t)i * M + j], min_conf);
-                }
-            }
-        }
-        const bool any = __ballot(acc) != 0ull;
-        if (lane == 0) occ[wave] = any ? 1 : 0;
-    }
-    __syncthreads();
-    int todo = 0;
-#pragma unroll
-    for (int w = 0; w < PD_TPW; w++) todo |= occ[w] << w;
-    if (!todo) return;                               // four empty tiles of the Bump image: nothing to draw
-    const GLOBAL_AS uint16_t *__restrict__ Bump = (const GLOBAL_AS uint16_t *)T.Bump[plane];
-    const BumpParam Q = load_param(T.Param[plane]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0u;
+    const uint32_t total = *count;
+    const uint32_t tiles_per_plane = (uint32_t)tiles_x * (uint32_t)bands;
     const uint32_t Qn = (uint32_t)(N - 1) * (uint32_t)(M - 1);
-    for (int w = 0; w < PD_TPW; w++) {
-        if (!((todo >> w) & 1)) continue;            // uniform over the workgroup
-        const int j0 = (blockIdx.x * PD_TPW + w) * 64;
+    for (uint32_t qi = blockIdx.x; qi < total; qi += gridDim.x) {
+        const uint32_t tile = queue[qi];
+        const int plane = plane_lo + (int)(tile / tiles_per_plane);
+        const uint32_t rem = tile % tiles_per_plane;
+        const int i0 = (int)(rem / (uint32_t)tiles_x) * PD_ROWS, j0 = (int)(rem % (uint32_t)tiles_x) * 64;
+        const GLOBAL_AS uint16_t *__restrict__ Bump = (const GLOBAL_AS uint16_t *)T.Bump[plane];
+        const GLOBAL_AS uint8_t *__restrict__ Maskb = (const GLOBAL_AS uint8_t *)T.Mask[plane];
+        const BumpParam Q = load_param(T.Param[plane]);
         for (int e = threadIdx.x; e < (PD_ROWS + 1) * 65; e += 256) {
             const int r = e / 65, cc = e % 65, i = i0 + r, j = j0 + cc;
             uint8_t mk = 0;
@@ -199,9 +218,31 @@ extern "C" int rgbdslam_planes_draw(rgbdslam_ctx *ctx, uint64_t *zbuf, uint16_t 
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = pose_world_to_cam16_host[k];
     PlaneTabs T = {(const uint16_t *const *)BumpTab, (const uint8_t *const *)RGBTab, (const uint8_t *const *)MaskTab, (const float *const *)ParamTab};
-    dim3 grid(((M_prim - 1 + 63) / 64 + PD_TPW - 1) / PD_TPW, (N_prim - 1 + PD_ROWS - 1) / PD_ROWS, (unsigned)(plane_hi - plane_lo));
-    KLAUNCH(ctx, k_planes_draw, grid, dim3(256), (unsigned long long *)zbuf, T, plane_lo, P, ctx->calib, N_prim, M_prim, (int)min_conf,
-            thresh, znear, zfar, n, m);
+    // scratch owned by the context (grown on demand; never shrinks): one stamp word per tile, the queue of occupied tiles,
+    // two counters (call parity)
+    const int planes = plane_hi - plane_lo;
+    const int tiles_x = (M_prim - 1 + 63) / 64, bands = (N_prim - 1 + PD_ROWS - 1) / PD_ROWS, pieces = (M_prim + 15) / 16;
+    const size_t tiles = (size_t)planes * tiles_x * bands;
+    if (tiles > 0x7FFFFFFFull || (size_t)pieces * bands > 0x7FFFFFFFull) return RGBDSLAM_E_LIMIT;
+    if (tiles > ctx->pd_cap) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pd_scratch) { (void)hipFree(ctx->pd_scratch); ctx->pd_scratch = nullptr; ctx->pd_cap = 0; }
+        void *ptr = nullptr;
+        HIP_TRY(hipMalloc(&ptr, 256 + 8 * tiles));
+        HIP_TRY(hipMemsetAsync(ptr, 0, 256 + 8 * tiles, ctx->stream));
+        ctx->pd_scratch = (uint32_t *)ptr; ctx->pd_cap = tiles; ctx->pd_stamp = 0;
+    }
+    if (++ctx->pd_stamp == 0u) {                       // the stamp wrapped: the tile words start again
+        HIP_TRY(hipMemsetAsync(ctx->pd_scratch + 64, 0, 4 * ctx->pd_cap, ctx->stream));
+        ctx->pd_stamp = 1u;
+    }
+    uint32_t *cnt = ctx->pd_scratch + 32 * (ctx->pd_stamp & 1u), *cnt_next = ctx->pd_scratch + 32 * ((ctx->pd_stamp + 1u) & 1u);
+    uint32_t *flags = ctx->pd_scratch + 64, *queue = flags + ctx->pd_cap;
+    KLAUNCH(ctx, k_planes_scan, dim3((unsigned)(((size_t)pieces * bands + 255) / 256), (unsigned)planes), dim3(256), T, plane_lo, N_prim, M_prim,
+            (int)min_conf, pieces, bands, tiles_x, flags, queue, cnt, ctx->pd_stamp);
+    KLAUNCH(ctx, k_planes_draw, dim3((unsigned)(tiles < PD_DRAW_WGS ? tiles : PD_DRAW_WGS)), dim3(256), (unsigned long long *)zbuf, T, plane_lo, P,
+            ctx->calib, N_prim, M_prim, (int)min_conf, thresh, znear, zfar, n, m, bands, tiles_x, queue, cnt, cnt_next);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -53,6 +53,32 @@ def test_labels_of_a_tiled_model(ctx, orc, pair, synth):
     assert torch.equal(lab, lab2)
 
 
+@pytest.mark.parametrize("variant", ["overlap_jitter", "interleaved", "mirrored"])
+def test_labels_first_match_order_on_hard_models(ctx, orc, pair, synth, variant):
+    """k_label_planes_l16 walks RUNS of planes that share an equation and, inside a run, only the members whose extent can
+    meet the wave's pixels.  The first match in PLANE order must survive that: 300 planes (two LDS chunks) whose patches
+    overlap at jittered shifts, the same set with the three walls interleaved plane by plane (every run has length one), and
+    patches with a negative scale (mirrored extent)."""
+    n, m = 480, 640
+    rng = np.random.default_rng(11)
+    base = synth.tiled_planes(PLANES, N)
+    params = np.concatenate([base, base[rng.integers(0, PLANES, 44)]]).copy()          # 300 planes, duplicates included
+    params[:, 6:8] += rng.uniform(-0.6, 0.6, (params.shape[0], 2)).astype(np.float32)  # overlapping patches
+    if variant == "interleaved":
+        params = params[rng.permutation(params.shape[0])]
+    if variant == "mirrored":
+        sel = rng.random(params.shape[0]) < 0.3
+        params[sel, 4] *= -1.0
+        params[sel, 6] += 2.0 * N / 500.0          # the mirrored patch covers the same strip
+    P = pose16(pair["R1"], pair["t1"])
+    g_param = dev(params)
+    lab = torch.empty(n, m, dtype=torch.int16, device="cuda")
+    ctx.label_planes_l16(lab, dev(pair["v0"]), dev(pair["n0"]), P, None, _tab(g_param), params.shape[0], N, N, n, m)
+    want = orc.label_planes_l16(pair["v0"], pair["n0"], P, list(params), N, N)
+    same(host(lab).view(np.uint16), want)
+    assert (want > 0).mean() > 0.5 and len(np.unique(want)) >= 8
+
+
 def test_fusion_into_256_planes_partition_equals_single_launch_and_oracle(ctx, orc, pair, synth, pkg):
     multigpu = __import__("importlib").import_module("rgb-d-slam_amd.multigpu")
     n, m = 480, 640
