@@ -256,62 +256,108 @@ def run_planes(args, env):
         ctx = pkg.Context(local, stream.cuda_stream)
         ctx.set_calibration_matrix(calib)
         shard = multigpu.PlaneShard(ctx, synth.tiled_planes(planes, N), N, rank, world)
-        pack = multigpu.FramePack(n, m)
-        rg = None
+        thin = args.pack == "thin"
+        pipelined = bool(args.pipeline)
+        # Pipelined step: rank 0 tracks frame f + 1 on a stream of its own (track_stream) while every rank --
+        # rank 0 included -- fuses / decodes / predicts frame f on the work stream; two packs alternate, ordered by events.
+        # The step time is then max(track, broadcast + work / N) instead of their sum.
+        packs = [multigpu.FramePack(n, m, thin=thin) for _ in range(2 if pipelined else 1)]
+        pack = packs[0]
+        track_stream = torch.cuda.Stream() if (pipelined and rank == 0) else stream
+        ev_ready = [torch.cuda.Event() for _ in packs]
+        ev_free = [torch.cuda.Event() for _ in packs]
+        free_recorded = [False for _ in packs]
+        rg = rg_ctx = None
         if rank == 0:
             pool = synth.sequence(POOL_FRAMES, n, m, calib, noise_sigma=0.001, seed=0)
             depth_dev = [torch.from_numpy(p[0]).cuda() for p in pool]
             bgr_dev = [torch.from_numpy(p[1]).cuda() for p in pool]
-            rg = pkg.RG(n, m, calib, device=local, stream=stream.cuda_stream)
+            rg = pkg.RG(n, m, calib, device=local, stream=track_stream.cuda_stream)
             rg.set_finish(False)                     # the model lives in the plane shards, not in the tracker's own Graph
+            rg_ctx = rg.context()                    # label + export run on the tracker's stream
             if world == 1 or "RGBDSLAM_BENCH_DEVICE" not in os.environ:
                 try:
                     rg.set_icp_loop(bool(args.icp_loop))
                 except RuntimeError:
                     pass
         order, k, d = [], 0, 1
-        for _ in range(2 * (args.warmup + args.steps) + 2 + 5 * 20):    # timed pass, phase pass, one short pass per profiled kernel
+        for _ in range(2 * (args.warmup + args.steps) + 4 + 6 * 20):    # timed pass, phase pass, one short pass per profiled kernel
             order.append(k)
             if k + d < 0 or k + d >= POOL_FRAMES:
                 d = -d
             k += d
-        pos = [0]
-        step_no = [0]
+        tracked_no = [0]                             # frames handed to the tracker so far (rank 0)
+        step_no = [0]                                # frames fused so far (every rank)
         view_w2c = []
         for R_, t_ in synth.trajectory(POOL_FRAMES, 0):
             Pw = np.eye(4)
             Pw[:3, :3] = R_.T
             Pw[:3, 3] = -R_.T @ t_
             view_w2c.append(np.ascontiguousarray(Pw.T.reshape(-1), np.float32))    # column-major 4x4
-        ev = {}
+        torch.cuda.synchronize()
 
-        def step(mark=None):
-            if rank == 0:
-                i = order[pos[0]]
-                pos[0] += 1
-                if mark:
-                    mark("t0")
-                rg.load_frame_device(depth_dev[i], bgr_dev[i])
-                rg.step_async()
-                rg.export_frame(pack.buf, pack.off_vmap, pack.off_rgbd, pack.off_mask, pack.off_hist)
-                shard.label(pack, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0])
-                if mark:
-                    mark("t1")
-            pack.broadcast(0)
+        def track(mark=None):
+            """rank 0: track + label + export of the next frame into its pack, on the tracker's stream"""
+            f = tracked_no[0]
+            tracked_no[0] += 1
+            pk = packs[f % len(packs)]
+            b = f % len(packs)
+            if pipelined and free_recorded[b]:
+                track_stream.wait_event(ev_free[b])              # the work of two frames ago has read this pack
             if mark:
-                mark("t2")
-            shard.fuse_and_decode(pack)
+                mark("k0", track_stream)
+            i = order[f]
+            rg.load_frame_device(depth_dev[i], bgr_dev[i])
+            rg.step_async()
+            if thin:
+                rg.export_frame_thin(pk.buf, pk.off_w, pk.off_rgb8, pk.off_mask, pk.off_hist)
+            else:
+                rg.export_frame(pk.buf, pk.off_vmap, pk.off_rgbd, pk.off_mask, pk.off_hist)
+            shard.label(pk, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0], ctx=rg_ctx)
             if mark:
-                mark("t3")
+                mark("k1", track_stream)
+            if pipelined:
+                ev_ready[b].record(track_stream)
+
+        def work(mark=None):
+            """every rank: broadcast of the frame's pack, fusion into + decode of the owned planes, prediction from them"""
+            f = step_no[0]
+            step_no[0] += 1
+            b = f % len(packs)
+            pk = packs[b]
+            if pipelined and rank == 0:
+                stream.wait_event(ev_ready[b])
+            if mark:
+                mark("t1", stream)
+            pk.broadcast(0)
+            if mark:
+                mark("t2", stream)
+            shard.fuse_and_decode(pk)
+            if mark:
+                mark("t3", stream)
             if args.planes_predict:
                 # the "raycast" half of configs[2]: the view of the frame just fused, predicted from the planes.  The view is
                 # the synthetic trajectory's pose of that frame (known to every rank without reading the tracked pose
                 # back from rank 0's device: nothing here waits for the GPU)
-                shard.predict(view_w2c[order[step_no[0] % len(order)]], n, m)
-            step_no[0] += 1
+                shard.predict(view_w2c[order[f]], n, m)
             if mark:
-                mark("t4")
+                mark("t4", stream)
+            if pipelined:
+                ev_free[b].record(stream)
+                free_recorded[b] = True
 
+        def step(mark=None):
+            if pipelined:
+                if rank == 0:
+                    track(mark)                      # frame f + 1, enqueued first: it runs beside the work on frame f
+                work(mark)
+            else:
+                if rank == 0:
+                    track(mark)
+                work(mark)
+
+        if pipelined and rank == 0:
+            track()                                  # prologue: frame 0 (the tracker stays one frame ahead from here on)
         for _ in range(1 + args.warmup):
             step()
         _barrier(env)
@@ -319,6 +365,7 @@ def run_planes(args, env):
         for _ in range(args.steps):
             step()
         stream.synchronize()
+        track_stream.synchronize()
         _barrier(env)
         dt = _max_over_ranks(env, time.perf_counter() - t0)
         tracked = 0
@@ -328,26 +375,34 @@ def run_planes(args, env):
             tracked = int((h[:, 12] == 1.0).sum())
             if tracked != args.steps:
                 raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
-        # ---- second pass (untimed): phases by events on rank 0's stream, decode kernel by the library's event hook ----
+            if args.icp_loop and rg.icp_loop_faults():
+                raise SystemExit("the persistent ICP kernel gave up waiting for its grid: result invalid")
+        # ---- second pass (untimed): phases by events on rank 0's streams, decode kernel by the library's event hook ----
         phases = None
         marks = []
 
-        def mark(name):
+        def mark(name, on):
             e = torch.cuda.Event(enable_timing=True)
-            e.record(stream)
+            e.record(on)
             marks.append((name, e))
         reps = min(args.steps, 50)
         tot_ms, launches = _profile(lib, ctx._h, "k_vertex_from_bump_batch", lambda: [step(mark if rank == 0 else None) for _ in range(reps)])
         stream.synchronize()
+        track_stream.synchronize()
         if rank == 0:
             acc = {"track_label_export": 0.0, "broadcast": 0.0, "fuse_decode": 0.0, "predict_draw_merge_resolve": 0.0}
-            for q in range(0, len(marks), 5):
-                acc["track_label_export"] += marks[q][1].elapsed_time(marks[q + 1][1])
-                acc["broadcast"] += marks[q + 1][1].elapsed_time(marks[q + 2][1])
-                acc["fuse_decode"] += marks[q + 2][1].elapsed_time(marks[q + 3][1])
-                acc["predict_draw_merge_resolve"] += marks[q + 3][1].elapsed_time(marks[q + 4][1])
+            by = {}
+            for name, e in marks:
+                by.setdefault(name, []).append(e)
+            for q in range(reps):
+                acc["track_label_export"] += by["k0"][q].elapsed_time(by["k1"][q])
+                acc["broadcast"] += by["t1"][q].elapsed_time(by["t2"][q])
+                acc["fuse_decode"] += by["t2"][q].elapsed_time(by["t3"][q])
+                acc["predict_draw_merge_resolve"] += by["t3"][q].elapsed_time(by["t4"][q])
             phases = {k_: round(v / reps * 1e3, 1) for k_, v in acc.items()}
-            phases["unit"] = "us per step on rank 0 (event pairs on its stream, second pass)"
+            phases["work_stream_total"] = round(by["t1"][0].elapsed_time(by["t4"][reps - 1]) / reps * 1e3, 1)
+            phases["unit"] = ("us per step on rank 0 (event pairs, second pass); pipelined: track_label_export runs on the tracker's stream "
+                              "beside the other three" if pipelined else "us per step on rank 0 (event pairs on its stream, second pass)")
         # the other kernels of the step, one profiled pass each (the library's hook follows one kernel name at a time)
         planes_kernels = []
         ev0 = C.c_double()
@@ -355,7 +410,8 @@ def run_planes(args, env):
         usable = int((shard.mask > 10).sum()) + int((shard.mask == 1).sum())
         owned_cells = (shard.hi - shard.lo) * N * N
         occupied_tiles = int((shard.mask.view(-1, N // 8, 8, N // 64, 64) > 10).any(dim=4).any(dim=2).sum()) if shard.hi > shard.lo else 0
-        extra = [("k_update<true>", (12 + 16 + 1 + 2 + 10) * n * m, "Graph::Update apply pass, u16 labels: 41 B per frame pixel")]
+        extra = [("k_update_thin<true>", (4 + 3 + 1 + 2 + 10) * n * m, "Graph::Update apply pass from the thin pack, u16 labels: 20 B per frame pixel") if thin else
+                 ("k_update<true>", (12 + 16 + 1 + 2 + 10) * n * m, "Graph::Update apply pass, u16 labels: 41 B per frame pixel")]
         if args.planes_predict:
             covered = int((shard.pred_v[..., 2] != 0).sum()) if getattr(shard, "pred_v", None) is not None else 0
             extra += [("k_planes_scan", owned_cells, "1 B mask per owned cell: every byte has to be looked at, no occupancy is kept between calls"),
@@ -365,8 +421,10 @@ def run_planes(args, env):
         # (every rank walks the same list: each pass runs steps, and a step holds collectives; the label kernel only runs on rank 0)
         extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
         for kname, nbytes, what in extra:
-            t_ms, cnt = _profile(lib, ctx._h, kname, lambda: [step() for _ in range(min(reps, 20))])
+            kctx = rg_ctx._h if (kname == "k_label_planes_l16" and rank == 0) else ctx._h      # the label kernel runs on the tracker's context
+            t_ms, cnt = _profile(lib, kctx, kname, lambda: [step() for _ in range(min(reps, 20))])
             stream.synchronize()
+            track_stream.synchronize()
             if cnt == 0:
                 continue
             us = max(1e-3, (t_ms / cnt - ev0.value) * 1e3)
@@ -397,11 +455,12 @@ def run_planes(args, env):
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[2]: 256 planes x 512x512 Bump cells tiled over the three planes of the synthetic room "
-                                      "corner; per step rank 0 tracks one 640x480 frame, labels it (u16) and broadcasts VMap/RGBD/Mask/Label/pose "
+                                      "corner; per step rank 0 tracks one 640x480 frame, labels it (u16) and broadcasts " + ("RGBD.w/colour bytes" if thin else "VMap/RGBD") + "/Mask/Label/pose "
                                       "(%d bytes), every rank fuses it into and decodes the planes it owns%s" % (pack.nbytes,
                                       ", then draws them into a u64 z-buffer for the frame's view, all-reduce(MIN) of %d bytes, resolve" % (8 * n * m)
                                       if args.planes_predict else ""),
-                          "planes_per_rank": shard.hi - shard.lo, "broadcast_bytes": pack.nbytes, "backend": env["backend"],
+                          "planes_per_rank": shard.hi - shard.lo, "broadcast_bytes": pack.nbytes, "pack": args.pack,
+                          "pipelined": pipelined, "backend": env["backend"],
                           "frames_resident_in_hbm": True},
                "roofline": {"bound": "hbm", "kernel": "k_vertex_from_bump_batch", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -528,6 +587,12 @@ def main():
     ap.add_argument("--planes-predict", type=int, default=1,
                     help="planes mode: 1 (default) = every step also predicts the frame's view from the planes (draw + all-reduce(MIN) + "
                          "resolve, the raycast half of configs[2]); 0 = fusion + decode only")
+    ap.add_argument("--pack", default="thin", choices=["thin", "fat"],
+                    help="planes mode: what rank 0 broadcasts per frame: thin (default) = RGBD.w + colour bytes + Mask + Label (10 B/px; every "
+                         "rank rebuilds VMap / RGBD.rgb), fat = VMap + RGBD + Mask + Label (31 B/px, rounds 1-2)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="planes mode: 1 (default) = rank 0 tracks frame f+1 on its own stream beside the fusion / decode / prediction of "
+                         "frame f; 0 = one stream, the phases one after the other")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer"],
                     help="rows mode: how the 27 partial sums travel (torch.distributed all-gather, or peer-mapped slots)")
     ap.add_argument("--rows", type=int, default=480)

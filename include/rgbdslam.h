@@ -531,6 +531,19 @@ int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float 
                               const float *pose16_host, const float *history_entry_dev, float **ParamTab, int nb_planes,
                               int N_prim, int M_prim, float epsilon, float alpha, int n, int m);
 
+/* Thin frame pack for the plane-partitioned multi-GPU form (no reference counterpart: the reference is single-GPU; SURVEY.md
+ * 8e row 1).  After PredictedFrame::Merge (Frame.cpp:300-333) the model VMap is VertexMapGL's function of RGBD.w
+ * (Kernel.cu:54-72) and RGBD.rgb is the frame's colour byte / 255 (Kernel.cu:463-465, 739-753), so the plane owners only need
+ * W = RGBD.w (f32), the colour bytes, Mask and the labels: 10 B per pixel instead of 31.  rgbdslam_export_thin writes those
+ * fields of a merged model frame; rgbdslam_update_from_history_thin_l16 is rgbdslam_update_from_history_l16 reading them
+ * (vertex and colour rebuilt with the reference's operations: the planes receive the same bits). */
+int rgbdslam_export_thin(rgbdslam_ctx *ctx, const float *RGBD, const uint8_t *Mask, float *W_out, uint8_t *RGB8_out,
+                         uint8_t *Mask_out, int n, int m);
+int rgbdslam_update_from_history_thin_l16(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
+                                          uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, const float *W,
+                                          const uint8_t *RGB8, const uint8_t *Mask, const uint16_t *Label16, int N_prim, int M_prim,
+                                          int n, int m, int plane_lo, int plane_hi);
+
 /* ---- the rest of the reference's operator headers: everything else its unchanged host code calls ---------------------
  * (so that integration/rgbdslam_shim.cpp defines every symbol Frame.cpp / Graph.cpp / RG.cpp reference) */
 /* Kernel.cuh:22  void MergeDepthKinect(float *RGB_predicted, unsigned short *depth, float *RGB, unsigned char *mask, int n, int m)

@@ -73,10 +73,19 @@ class Context:
         self._h = C.c_void_p()
         _chk(self.lib.rgbdslam_create(C.byref(self._h), int(device), C.c_void_p(stream or 0)), "rgbdslam_create")
 
+    @classmethod
+    def borrow(cls, handle):
+        """A Context over a rgbdslam_ctx that somebody else owns (e.g. the tracker's: RG.context()); close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.lib = load()
+        self._h = C.c_void_p(int(handle))
+        self._borrowed = True
+        return self
+
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             self.lib.rgbdslam_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -275,6 +284,16 @@ class Context:
                                                        _ptr(mask), _ptr(label16), N_prim, M_prim, n, m, plane_lo, plane_hi),
              "update_from_history_l16")
 
+    def update_from_history_thin_l16(self, hist, bump_tab, rgb_tab, mask_tab, param_tab, claim_tab, stamp, w, rgb8, mask, label16,
+                                     N_prim, M_prim, n, m, plane_lo=0, plane_hi=0x7FFFFFFF):
+        _chk(self.lib.rgbdslam_update_from_history_thin_l16(self._h, _ptr(hist), _ptr(bump_tab), _ptr(rgb_tab), _ptr(mask_tab),
+                                                            _ptr(param_tab), _ptr(claim_tab), C.c_uint32(stamp), _ptr(w), _ptr(rgb8),
+                                                            _ptr(mask), _ptr(label16), N_prim, M_prim, n, m, plane_lo, plane_hi),
+             "update_from_history_thin_l16")
+
+    def export_thin(self, rgbd, mask, w_out, rgb8_out, mask_out, n, m):
+        _chk(self.lib.rgbdslam_export_thin(self._h, _ptr(rgbd), _ptr(mask), _ptr(w_out), _ptr(rgb8_out), _ptr(mask_out), n, m), "export_thin")
+
     def label_planes_l16(self, label16, vmap, nmap, pose, hist, param_tab, nb, N_prim, M_prim, n, m, eps=0.1, alpha=0.8):
         _chk(self.lib.rgbdslam_label_planes_l16(self._h, _ptr(label16), _ptr(vmap), _ptr(nmap),
                                                 _host16(pose) if pose is not None else None, _ptr(hist), _ptr(param_tab), nb,
@@ -437,6 +456,10 @@ class RG:
         self.lib.slamhost_rg_ctx.restype = C.c_void_p
         return C.c_void_p(self.lib.slamhost_rg_ctx(self._h))
 
+    def context(self):
+        """The tracker's own rgbdslam_ctx (its stream, its calibration) as a borrowed Context."""
+        return Context.borrow(self._ctx_ptr().value)
+
     def set_icp_line_check(self, on):
         """Verify the integrity word of every line the ICP kernels hand between workgroups (rgbdslam_set_icp_line_check)."""
         _chk(load().rgbdslam_set_icp_line_check(self._ctx_ptr(), int(on)), "set_icp_line_check")
@@ -560,6 +583,11 @@ class RG:
         """Packs the merged model VMap / RGBD / Mask and the frame's history entry into `dst` (stream-ordered)."""
         _hchk(self.lib.slamhost_rg_export_frame(self._h, _ptr(dst), C.c_size_t(off_vmap), C.c_size_t(off_rgbd), C.c_size_t(off_mask),
                                                 C.c_size_t(off_hist)), "export_frame")
+
+    def export_frame_thin(self, dst, off_w, off_rgb8, off_mask, off_hist):
+        """Thin pack: RGBD.w (f32), the colour bytes, Mask and the history entry of the merged model frame (stream-ordered)."""
+        _hchk(self.lib.slamhost_rg_export_frame_thin(self._h, _ptr(dst), C.c_size_t(off_w), C.c_size_t(off_rgb8), C.c_size_t(off_mask),
+                                                     C.c_size_t(off_hist)), "export_frame_thin")
 
     def pose(self):
         R = (C.c_float * 9)()

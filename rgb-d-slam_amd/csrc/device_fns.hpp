@@ -522,9 +522,13 @@ struct UpdateArgs {
     const rgbdslam_pose_block *pb;
     const float *hist;
     int N_prim, M_prim, n, m, plane_lo, plane_hi;
+    // "thin" frame source (plane-partitioned multi-GPU): W non-null -> the vertex is VertexMapGL's function of the
+    // model depth W (Kernel.cu:54-72: what Merge left in VMap) and the colour the frame's byte / 255 (Kernel.cu:463-465, 739-753:
+    // what Merge left in RGBD.rgb); VMap / RGBD are then unused.  Same operations on the same operands: the same bits.
+    const float *W; const uint8_t *RGB8; CalibV c;
 };
 // one 64x4 tile (bx, by) of UpdateKernel; APPLY = second pass of the winner rule
-template <bool APPLY>
+template <bool APPLY, bool THIN = false>
 __device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, const int by) {
     uint16_t *const *__restrict__ BumpTab = a.BumpTab; uint8_t *const *__restrict__ RGBTab = a.RGBTab;
     uint8_t *const *__restrict__ MaskTab = a.MaskTab; float *const *__restrict__ ParamTab = a.ParamTab;
@@ -560,7 +564,7 @@ __device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, c
     const bool one_plane = __ballot(valid && L != L0) == 0ull;
     if (!valid) return;
     const uint8_t mc = Mask[idx];
-    const F3 p = xf_point(P.v, ld3(VMap, idx));
+    const F3 p = xf_point(P.v, THIN ? vertex_from_w(a.W[idx], i, j, a.c) : ld3(VMap, idx));
     UpdCell u;
     uint8_t *maskb;
     unsigned long long *claimb;
@@ -595,7 +599,9 @@ __device__ __forceinline__ void update_tile(const UpdateArgs &a, const int bx, c
         if (mref > 11) { *cellmask = (uint8_t)(mref - 1); }
         else { *cellmask = 10; B[0] = 0; B[1] = 0; B[2] = 0; C[0] = 0; C[1] = 0; C[2] = 0; }
     } else {
-        float4 col = *(const float4 *)(RGBD + 4 * idx);
+        float4 col;
+        if (THIN) { col.x = unorm8(a.RGB8[3 * idx]); col.y = unorm8(a.RGB8[3 * idx + 1]); col.z = unorm8(a.RGB8[3 * idx + 2]); col.w = 0.0f; }
+        else col = *(const float4 *)(RGBD + 4 * idx);
         B[0] = (uint16_t)f2i_rn((float)((double)u.sa * 60000.0));             // Primitive.cu:342-344
         B[1] = (uint16_t)f2i_rn((float)((double)u.sb * 60000.0));
         B[2] = (uint16_t)f2i_rn((float)(((double)u.err + 15.0) * 2000.0));

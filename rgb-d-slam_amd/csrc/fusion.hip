@@ -5,6 +5,8 @@
 // UpdateArgs / update_tile: device_fns.hpp (k_predict_draw carries apply tiles too)
 template <bool APPLY>
 __global__ void k_update(UpdateArgs a) { update_tile<APPLY>(a, blockIdx.x, blockIdx.y); }
+template <bool APPLY>
+__global__ void k_update_thin(UpdateArgs a) { update_tile<APPLY, true>(a, blockIdx.x, blockIdx.y); }   // frame read from a thin pack
 
 // Apply pass of Graph::Update for frame f AND OffLineFrame::LoadFrame of frame f+1 in one launch: the two are
 // independent (every reader of frame f's maps has finished before the apply pass starts), both are latency-bound, and
@@ -279,6 +281,52 @@ extern "C" int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *
     if (!history_entry_dev || !Label16) return RGBDSLAM_E_ARG;
     return launch_update(ctx, nullptr, history_entry_dev, BumpTab, RGBTab, MaskTab, ParamTab, ClaimTab, stamp, VMap, RGBD, Mask, nullptr,
                          nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi, Label16);
+}
+
+// ---- thin frame pack (plane-partitioned multi-GPU; no reference counterpart) ------------------------------------------------
+// What the plane owners need of a tracked frame that they cannot derive: the merged model depth RGBD.w (f32), the frame's colour
+// bytes, the confidence mask and the labels -- 10 B per pixel instead of the 31 B of VMap + RGBD + Mask + Label.  After Merge
+// (Frame.cpp:300-333) VMap is VertexMapGL(RGBD.w) (Kernel.cu:54-72) and RGBD.rgb is the frame's byte / 255 (Kernel.cu:463-465):
+// k_export_thin recovers the byte (rn(255 x) inverts x = b / 255 exactly), the update kernels rebuild both from the thin
+// fields with the reference's own operations.
+__global__ void k_export_thin(const float *__restrict__ RGBD, const uint8_t *__restrict__ Mask, float *__restrict__ W,
+                              uint8_t *__restrict__ RGB8, uint8_t *__restrict__ MaskOut, int n, int m) {
+    int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const size_t idx = (size_t)i * m + j;
+    const float4 v = *(const float4 *)(RGBD + 4 * idx);
+    W[idx] = v.w;
+    RGB8[3 * idx] = (uint8_t)f2i_rn((float)((double)v.x * 255.0));
+    RGB8[3 * idx + 1] = (uint8_t)f2i_rn((float)((double)v.y * 255.0));
+    RGB8[3 * idx + 2] = (uint8_t)f2i_rn((float)((double)v.z * 255.0));
+    MaskOut[idx] = Mask[idx];
+}
+extern "C" int rgbdslam_export_thin(rgbdslam_ctx *ctx, const float *RGBD, const uint8_t *Mask, float *W_out, uint8_t *RGB8_out,
+                                    uint8_t *Mask_out, int n, int m) {
+    if (!ctx || !RGBD || !Mask || !W_out || !RGB8_out || !Mask_out || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    KLAUNCH(ctx, k_export_thin, grid2d(n, m), block2d(), RGBD, Mask, W_out, RGB8_out, Mask_out, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// Graph::Update (claim + apply) from a thin pack, posed and gated by the frame's history entry, 16-bit labels.
+extern "C" int rgbdslam_update_from_history_thin_l16(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab,
+                                                     uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab,
+                                                     uint32_t stamp, const float *W, const uint8_t *RGB8, const uint8_t *Mask,
+                                                     const uint16_t *Label16, int N_prim, int M_prim, int n, int m, int plane_lo,
+                                                     int plane_hi) {
+    if (!ctx || !history_entry_dev || !BumpTab || !RGBTab || !MaskTab || !ParamTab || !ClaimTab || !W || !RGB8 || !Mask || !Label16)
+        return RGBDSLAM_E_ARG;
+    if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
+    if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    PoseV P;
+    for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, nullptr, nullptr, Mask, nullptr, Label16, P,
+                    nullptr, history_entry_dev, N_prim, M_prim, n, m, plane_lo, plane_hi, W, RGB8, ctx->calib};
+    KLAUNCH(ctx, k_update_thin<false>, grid2d(n, m), block2d(), a);
+    KLAUNCH(ctx, k_update_thin<true>, grid2d(n, m), block2d(), a);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // Labels by plane membership for tiled models (test / bench harness stand-in for plane detection, like rgbdslam_seed_labels):

@@ -1230,6 +1230,18 @@ void RG::ExportFrame(void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off
               "export history entry");
 }
 
+// The thin form of ExportFrame (rgbdslam_export_thin): RGBD.w, the colour bytes and the mask -- what the plane owners cannot
+// derive -- plus the history entry; one kernel and one 64-byte copy.
+void RG::ExportFrameThin(void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist) {
+    if (!dst_dev || frames_done == 0) throw Error("ExportFrameThin: no frame processed yet", RGBDSLAM_E_STATE);
+    hipStream_t s = ctx_stream(_ctx);
+    char *d = (char *)dst_dev;
+    check(rgbdslam_export_thin(_ctx, _predicted_frame->getRGB(), _predicted_frame->_Mask_dev, (float *)(d + off_w), (uint8_t *)(d + off_rgb8),
+                               (uint8_t *)(d + off_mask), _predicted_frame->_n, _predicted_frame->_m), "export_thin");
+    hip_check(hipMemcpyAsync(d + off_hist, _history_dev.p + 16 * (size_t)((frames_done - 1) % HISTORY_CAP), 64, hipMemcpyDeviceToDevice, s),
+              "export history entry");
+}
+
 const float *RG::history_host(int frame_index) { return _history_host + 16 * (size_t)(frame_index % HISTORY_CAP); }
 
 int RG::Step() {
@@ -1440,6 +1452,11 @@ int slamhost_rg_set_stream_events(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     if (((RG *)rg)->_count != 1) return RGBDSLAM_E_STATE;
     FACADE_TRY(((RG *)rg)->_frame->set_stream_events(on != 0));
+    return 0;
+}
+int slamhost_rg_export_frame_thin(void *rg, void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->ExportFrameThin(dst_dev, off_w, off_rgb8, off_mask, off_hist));
     return 0;
 }
 int slamhost_rg_get_pose(void *rg, float *R9_cm, float *t3) {

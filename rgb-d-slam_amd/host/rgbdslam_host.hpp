@@ -334,6 +334,9 @@ public:
     // model VMap, RGBD, Mask and the frame's history entry (pose + tracked flag) -- into one packed device buffer at the
     // given byte offsets, stream-ordered after the frame's kernels; the caller broadcasts that buffer.
     void ExportFrame(void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off_mask, size_t off_hist);
+    // the same for the thin pack (10 B per pixel): RGBD.w, colour bytes, Mask + the history entry; VMap and RGBD.rgb are
+    // functions of those (Kernel.cu:54-72, 463-465) and every plane owner rebuilds them
+    void ExportFrameThin(void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist);
 
     OffLineFrame *_frame;
     PredictedFrame *_predicted_frame;

@@ -159,16 +159,26 @@ class ShardedAligner:
 # ---- plane-partitioned fusion + decode (BASELINE configs[2]) -----------------------------------------------------------
 class FramePack:
     """What the plane owners need of one tracked frame, as ONE contiguous buffer so that the step's only collective is one
-    broadcast: merged model VMap (f32x3), RGBD (f32x4), the frame's history entry (poseR(9) poset(3) tracked ...: pose +
-    gate), Mask (u8) and the 16-bit label image.  30 B/px + 64 B = 9.2 MB at 640x480."""
+    broadcast.
+    thin (default): only what cannot be derived -- the merged model depth RGBD.w (f32), the frame's colour bytes (u8 x 3),
+    Mask (u8), the 16-bit label image and the frame's 64-byte history entry (pose + gate): 10 B/px = 3.1 MB at 640x480.  After
+    Merge the model VMap is VertexMapGL's function of RGBD.w (D1/Kernel.cu:54-72) and RGBD.rgb is the frame's byte / 255
+    (D1/Kernel.cu:463-465), so every rank rebuilds both with the reference's own operations: the same bits
+    (rgbdslam_update_from_history_thin_l16).
+    fat (thin=False, rounds 1-2): VMap (f32x3) and RGBD (f32x4) themselves: 31 B/px = 9.5 MB."""
 
-    def __init__(self, n, m, device="cuda"):
+    def __init__(self, n, m, device="cuda", thin=True):
         P = n * m
         up = lambda x: (x + 255) // 256 * 256
-        self.n, self.m = n, m
-        self.off_vmap = 0
-        self.off_rgbd = up(12 * P)
-        self.off_hist = up(self.off_rgbd + 16 * P)
+        self.n, self.m, self.thin = n, m, thin
+        if thin:
+            self.off_w = 0
+            self.off_rgb8 = up(4 * P)
+            self.off_hist = up(self.off_rgb8 + 3 * P)
+        else:
+            self.off_vmap = 0
+            self.off_rgbd = up(12 * P)
+            self.off_hist = up(self.off_rgbd + 16 * P)
         self.off_mask = self.off_hist + 256
         self.off_label = up(self.off_mask + P)
         self.nbytes = up(self.off_label + 2 * P)
@@ -183,6 +193,10 @@ class FramePack:
             return self.buf[self.off_vmap:self.off_vmap + 12 * P].view(torch.float32).view(self.n, self.m, 3)
         if name == "rgbd":
             return self.buf[self.off_rgbd:self.off_rgbd + 16 * P].view(torch.float32).view(self.n, self.m, 4)
+        if name == "w":
+            return self.buf[self.off_w:self.off_w + 4 * P].view(torch.float32).view(self.n, self.m)
+        if name == "rgb8":
+            return self.buf[self.off_rgb8:self.off_rgb8 + 3 * P].view(self.n, self.m, 3)
         if name == "hist":
             return self.buf[self.off_hist:self.off_hist + 64].view(torch.float32)
         if name == "mask":
@@ -227,18 +241,26 @@ class PlaneShard:
         self.t_param = torch.tensor([self.param[i].data_ptr() for i in range(self.nb)], dtype=torch.int64, device="cuda")
         self.stamp = 0
 
-    def label(self, pack, vmap_ptr, nmap_ptr, eps=0.1, alpha=0.8):
-        """Tracking rank only: 16-bit labels of the model frame by plane membership, posed by the pack's history entry."""
-        self.ctx.label_planes_l16(pack.ptr(pack.off_label), vmap_ptr, nmap_ptr, None, pack.ptr(pack.off_hist), self.t_param, self.nb,
-                                  self.N, self.N, pack.n, pack.m, eps, alpha)
+    def label(self, pack, vmap_ptr, nmap_ptr, eps=0.1, alpha=0.8, ctx=None):
+        """Tracking rank only: 16-bit labels of the model frame by plane membership, posed by the pack's history entry.
+        ctx: the context (stream) to run on -- the tracker's own in the pipelined step."""
+        (ctx or self.ctx).label_planes_l16(pack.ptr(pack.off_label), vmap_ptr, nmap_ptr, None, pack.ptr(pack.off_hist), self.t_param,
+                                           self.nb, self.N, self.N, pack.n, pack.m, eps, alpha)
 
     def fuse_and_decode(self, pack):
         """Graph::Update (claim + apply) of the owned planes from the broadcast frame, then VertexFromBump of the owned planes."""
         self.stamp += 1
         if self.hi > self.lo:
-            self.ctx.update_from_history_l16(pack.ptr(pack.off_hist), self.t_bump, self.t_rgb, self.t_mask, self.t_param, self.t_claim,
-                                             self.stamp, pack.ptr(pack.off_vmap), pack.ptr(pack.off_rgbd), pack.ptr(pack.off_mask),
-                                             pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m, self.lo, self.hi)
+            if pack.thin:
+                self.ctx.update_from_history_thin_l16(pack.ptr(pack.off_hist), self.t_bump, self.t_rgb, self.t_mask, self.t_param,
+                                                      self.t_claim, self.stamp, pack.ptr(pack.off_w), pack.ptr(pack.off_rgb8),
+                                                      pack.ptr(pack.off_mask), pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m,
+                                                      self.lo, self.hi)
+            else:
+                self.ctx.update_from_history_l16(pack.ptr(pack.off_hist), self.t_bump, self.t_rgb, self.t_mask, self.t_param,
+                                                 self.t_claim, self.stamp, pack.ptr(pack.off_vmap), pack.ptr(pack.off_rgbd),
+                                                 pack.ptr(pack.off_mask), pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m,
+                                                 self.lo, self.hi)
             self.ctx.vertex_from_bump_batch(self.t_vout, self.t_cout, self.t_kout, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
                                             self.lo, self.hi, self.N, self.N)
 

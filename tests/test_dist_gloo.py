@@ -164,7 +164,7 @@ def _plane_step_broadcast(rank, world):
     orc, synth, calib, s = _scene(n, m)
     params = synth.tiled_planes(nb, N)
     pose = np.eye(4, dtype=np.float32).T.reshape(-1)
-    pack = mg.FramePack(n, m, device="cpu")
+    pack = mg.FramePack(n, m, device="cpu", thin=False)
     hist = np.zeros(16, np.float32)
     hist[:9] = np.eye(3, dtype=np.float32).reshape(-1); hist[12] = 1.0
     label = orc.label_planes_l16(s["v0"], s["n0"], pose, list(params), N, N)

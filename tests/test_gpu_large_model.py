@@ -138,3 +138,51 @@ def test_fusion_into_256_planes_partition_equals_single_launch_and_oracle(ctx, o
         same(host(cout[k]), rc)
         same(host(kout[k]), rk)
     assert float(vout[untouched].abs().max()) == 0.0
+
+
+def test_thin_pack_update_equals_fat_update(ctx, orc, pair, synth):
+    """The thin frame pack (RGBD.w + colour bytes + Mask + Label, 10 B/px): rgbdslam_export_thin of a MERGED model frame, then
+    rgbdslam_update_from_history_thin_l16 -- which rebuilds the vertex with VertexMapGL's arithmetic (Kernel.cu:54-72) and the
+    colour as byte / 255 (Kernel.cu:463-465) -- must leave the planes exactly as rgbdslam_update_from_history_l16 does from the
+    full VMap / RGBD, and as the oracle does."""
+    n, m = 480, 640
+    calib = synth.TUM_CALIB
+    params = synth.tiled_planes(PLANES, N)
+    g_param = dev(params)
+    # a merged model frame: VMap is VertexMapGL of RGBD.w, RGBD.rgb the frame's colour bytes / 255
+    rgbd = pair["rgbd0"].copy()
+    vmap = orc.vertex_map_gl(rgbd, calib)
+    nmap = orc.compute_normal(vmap)
+    rng = np.random.default_rng(3)
+    mask = rng.integers(9, 40, (n, m)).astype(np.uint8)
+    R, t = np.asarray(pair["R1"], np.float32), np.asarray(pair["t1"], np.float32)
+    hist = np.zeros(16, np.float32)
+    hist[:9] = R.T.reshape(-1); hist[9:12] = t; hist[12] = 1.0
+    P = pose16(R, t)
+    label = orc.label_planes_l16(vmap, nmap, P, list(params), N, N)
+    g = {k: dev(v) for k, v in dict(v=vmap, rgbd=rgbd, mask=mask, lab=label.view(np.int16), hist=hist).items()}
+    w = torch.empty(n, m, device="cuda"); rgb8 = torch.empty(n, m, 3, dtype=torch.uint8, device="cuda"); mk2 = torch.empty(n, m, dtype=torch.uint8, device="cuda")
+    ctx.export_thin(g["rgbd"], g["mask"], w, rgb8, mk2, n, m)
+    assert torch.equal(w, g["rgbd"][..., 3]) and torch.equal(mk2, g["mask"])
+    assert np.array_equal(host(rgb8), np.rint(rgbd[..., :3].astype(np.float64) * 255.0).astype(np.uint8))
+    assert np.array_equal(host(rgb8).astype(np.float32) / np.float32(255.0), rgbd[..., :3])       # the byte gives the float back
+    models = []
+    for thin in (False, True):
+        bump, rgbb, mk, claim = _model()
+        tabs = [_tab(x) for x in (bump, rgbb, mk, g_param, claim)]
+        for stamp in (1, 2):                                     # twice: the second pass meets non-empty cells (gate, erosion)
+            if thin:
+                ctx.update_from_history_thin_l16(g["hist"], *tabs, stamp, w, rgb8, mk2, g["lab"], N, N, n, m)
+            else:
+                ctx.update_from_history_l16(g["hist"], *tabs, stamp, g["v"], g["rgbd"], g["mask"], g["lab"], N, N, n, m)
+        ctx.synchronize()
+        models.append((bump, rgbb, mk))
+    for a, b in zip(models[0], models[1]):
+        assert torch.equal(a, b)
+    assert int((models[1][2] > 10).sum()) > 100000
+    # a lost frame (history entry not tracked) leaves the planes alone
+    bump, rgbb, mk, claim = _model(4)
+    hist[12] = 0.0
+    ctx.update_from_history_thin_l16(dev(hist), *[_tab(x) for x in (bump, rgbb, mk, g_param[:4].contiguous(), claim)], 1, w, rgb8, mk2, g["lab"], N, N, n, m)
+    ctx.synchronize()
+    assert bool((mk == 10).all())

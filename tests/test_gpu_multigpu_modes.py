@@ -109,8 +109,13 @@ def test_rows_mode_three_ranks_one_of_them_delayed():
 
 def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():
     args = ["--mode", "planes", "--steps", "6", "--warmup", "2"]
-    one = _bench(args)
+    one = _bench(args)                                           # thin pack, tracking pipelined with the fusion (the defaults)
     two = _bench(args, world=2)
+    # rounds 1-2's form -- VMap / RGBD broadcast as they are, one stream, the phases one after the other -- leaves the same
+    # model and predicts the same view: what the thin pack drops is rebuilt bit for bit, and the pipeline reorders nothing
+    fat = _bench(args + ["--pack", "fat", "--pipeline", "0"])
+    assert fat["config"]["broadcast_bytes"] > 3 * one["config"]["broadcast_bytes"] and one["config"]["pipelined"] and not fat["config"]["pipelined"]
+    assert (fat["model_checksum"], fat["cells_fused"], fat["prediction_checksum"]) == (one["model_checksum"], one["cells_fused"], one["prediction_checksum"])
     assert one["config"]["planes_per_rank"] == 256 and two["config"]["planes_per_rank"] == 128
     assert one["cells_fused"] > 100000
     assert (one["model_checksum"], one["cells_fused"]) == (two["model_checksum"], two["cells_fused"])
