@@ -255,7 +255,12 @@ def run_planes(args, env):
     with torch.cuda.stream(stream):
         ctx = pkg.Context(local, stream.cuda_stream)
         ctx.set_calibration_matrix(calib)
-        shard = multigpu.PlaneShard(ctx, synth.tiled_planes(planes, N), N, rank, world)
+        # from four ranks on the tracking rank owns no planes (auto): its frame time bounds the step then, and beside the tracker a
+        # share of the decode would make it the straggler (scaling table)
+        first_worker = {"auto": 1 if world >= 4 else 0, "1": 0, "0": 1}[args.tracker_works]
+        if first_worker >= world:
+            first_worker = 0
+        shard = multigpu.PlaneShard(ctx, synth.tiled_planes(planes, N), N, rank, world, first_worker=first_worker)
         thin = args.pack == "thin"
         pipelined = bool(args.pipeline)
         # Pipelined step: rank 0 tracks frame f + 1 on a stream of its own (track_stream) while every rank --
@@ -264,8 +269,18 @@ def run_planes(args, env):
         packs = [multigpu.FramePack(n, m, thin=thin) for _ in range(2 if pipelined else 1)]
         pack = packs[0]
         track_stream = torch.cuda.Stream() if (pipelined and rank == 0) else stream
-        ev_ready = [torch.cuda.Event() for _ in packs]
-        ev_free = [torch.cuda.Event() for _ in packs]
+        # pipelined: the broadcast has a stream of its own (the tracker goes on with the next frame while the pack travels), and
+        # so has the prediction (it only READS the planes, like the decode: the two run side by side after the fusion)
+        comm_stream = torch.cuda.Stream() if pipelined else stream
+        pred_stream = torch.cuda.Stream() if (pipelined and args.planes_predict) else stream
+        ctx_pred = ctx
+        if pred_stream is not stream:
+            ctx_pred = pkg.Context(local, pred_stream.cuda_stream)
+            ctx_pred.set_calibration_matrix(calib)
+        ev_exported = [torch.cuda.Event() for _ in packs]    # tracker -> comm: the pack is filled (rank 0)
+        ev_ready = [torch.cuda.Event() for _ in packs]       # comm -> work: the pack has arrived
+        ev_free = [torch.cuda.Event() for _ in packs]        # work -> tracker / comm: the fusion has read the pack
+        ev_fused, ev_pred = torch.cuda.Event(), torch.cuda.Event()
         free_recorded = [False for _ in packs]
         rg = rg_ctx = None
         if rank == 0:
@@ -281,12 +296,12 @@ def run_planes(args, env):
                 except RuntimeError:
                     pass
         order, k, d = [], 0, 1
-        for _ in range(2 * (args.warmup + args.steps) + 4 + 6 * 20):    # timed pass, phase pass, one short pass per profiled kernel
+        for _ in range(2 * (args.warmup + args.steps) + 4 + 7 * 20):    # timed pass, phase pass, one short pass per profiled kernel
             order.append(k)
             if k + d < 0 or k + d >= POOL_FRAMES:
                 d = -d
             k += d
-        tracked_no = [0]                             # frames handed to the tracker so far (rank 0)
+        tracked_no = [0]                             # frames handed to the tracker / the broadcast so far
         step_no = [0]                                # frames fused so far (every rank)
         view_w2c = []
         for R_, t_ in synth.trajectory(POOL_FRAMES, 0):
@@ -296,76 +311,94 @@ def run_planes(args, env):
             view_w2c.append(np.ascontiguousarray(Pw.T.reshape(-1), np.float32))    # column-major 4x4
         torch.cuda.synchronize()
 
-        def track(mark=None):
-            """rank 0: track + label + export of the next frame into its pack, on the tracker's stream"""
+        def track_and_send(mark=None):
+            """the next frame: rank 0 tracks, labels and exports it into its pack (tracker's stream); every rank takes part in
+            the pack's broadcast (comm stream)"""
             f = tracked_no[0]
             tracked_no[0] += 1
-            pk = packs[f % len(packs)]
             b = f % len(packs)
-            if pipelined and free_recorded[b]:
-                track_stream.wait_event(ev_free[b])              # the work of two frames ago has read this pack
+            pk = packs[b]
+            if rank == 0:
+                if pipelined and free_recorded[b]:
+                    track_stream.wait_event(ev_free[b])          # the fusion of two frames ago has read this pack
+                if mark:
+                    mark("k0", track_stream)
+                i = order[f]
+                rg.load_frame_device(depth_dev[i], bgr_dev[i])
+                rg.step_async()
+                if thin:
+                    rg.export_frame_thin(pk.buf, pk.off_w, pk.off_rgb8, pk.off_mask, pk.off_hist)
+                else:
+                    rg.export_frame(pk.buf, pk.off_vmap, pk.off_rgbd, pk.off_mask, pk.off_hist)
+                shard.label(pk, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0], ctx=rg_ctx)
+                if mark:
+                    mark("k1", track_stream)
+                if pipelined:
+                    ev_exported[b].record(track_stream)
+                    comm_stream.wait_event(ev_exported[b])
+            elif pipelined and free_recorded[b]:
+                comm_stream.wait_event(ev_free[b])               # the pack may be overwritten
             if mark:
-                mark("k0", track_stream)
-            i = order[f]
-            rg.load_frame_device(depth_dev[i], bgr_dev[i])
-            rg.step_async()
-            if thin:
-                rg.export_frame_thin(pk.buf, pk.off_w, pk.off_rgb8, pk.off_mask, pk.off_hist)
-            else:
-                rg.export_frame(pk.buf, pk.off_vmap, pk.off_rgbd, pk.off_mask, pk.off_hist)
-            shard.label(pk, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0], ctx=rg_ctx)
+                mark("t1", comm_stream)
+            with torch.cuda.stream(comm_stream):
+                pk.broadcast(0)
             if mark:
-                mark("k1", track_stream)
+                mark("t2", comm_stream)
             if pipelined:
-                ev_ready[b].record(track_stream)
+                ev_ready[b].record(comm_stream)
 
         def work(mark=None):
-            """every rank: broadcast of the frame's pack, fusion into + decode of the owned planes, prediction from them"""
+            """every rank: fusion of the frame into the owned planes, then their decode and -- beside it -- the prediction"""
             f = step_no[0]
             step_no[0] += 1
             b = f % len(packs)
             pk = packs[b]
-            if pipelined and rank == 0:
+            if pipelined:
                 stream.wait_event(ev_ready[b])
             if mark:
-                mark("t1", stream)
-            pk.broadcast(0)
+                mark("w0", stream)
+            shard.fuse(pk)
+            if pipelined:
+                ev_free[b].record(stream)            # nothing after the fusion reads the pack
+                free_recorded[b] = True
             if mark:
-                mark("t2", stream)
-            shard.fuse_and_decode(pk)
+                mark("w1", stream)
+            if args.planes_predict and pred_stream is not stream:
+                ev_fused.record(stream)
+                pred_stream.wait_event(ev_fused)
+            shard.decode()
             if mark:
-                mark("t3", stream)
+                mark("w2", stream)
             if args.planes_predict:
                 # the "raycast" half of configs[2]: the view of the frame just fused, predicted from the planes.  The view is
                 # the synthetic trajectory's pose of that frame (known to every rank without reading the tracked pose
                 # back from rank 0's device: nothing here waits for the GPU)
-                shard.predict(view_w2c[order[f]], n, m)
+                if mark:
+                    mark("p0", pred_stream)
+                with torch.cuda.stream(pred_stream):
+                    shard.predict(view_w2c[order[f]], n, m, ctx=ctx_pred)
+                if mark:
+                    mark("p1", pred_stream)
+                if pred_stream is not stream:
+                    ev_pred.record(pred_stream)
+                    stream.wait_event(ev_pred)       # the next fusion writes the planes the prediction reads
             if mark:
-                mark("t4", stream)
-            if pipelined:
-                ev_free[b].record(stream)
-                free_recorded[b] = True
+                mark("w3", stream)
 
         def step(mark=None):
-            if pipelined:
-                if rank == 0:
-                    track(mark)                      # frame f + 1, enqueued first: it runs beside the work on frame f
-                work(mark)
-            else:
-                if rank == 0:
-                    track(mark)
-                work(mark)
+            track_and_send(mark)                     # pipelined: frame f + 1, enqueued first, beside the work on frame f
+            work(mark)
 
-        if pipelined and rank == 0:
-            track()                                  # prologue: frame 0 (the tracker stays one frame ahead from here on)
+        if pipelined:
+            track_and_send()                         # prologue: frame 0 (tracker and broadcast stay one frame ahead from here on)
         for _ in range(1 + args.warmup):
             step()
         _barrier(env)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        stream.synchronize()
-        track_stream.synchronize()
+        for st_ in (stream, track_stream, comm_stream, pred_stream):
+            st_.synchronize()
         _barrier(env)
         dt = _max_over_ranks(env, time.perf_counter() - t0)
         tracked = 0
@@ -389,20 +422,19 @@ def run_planes(args, env):
         tot_ms, launches = _profile(lib, ctx._h, "k_vertex_from_bump_batch", lambda: [step(mark if rank == 0 else None) for _ in range(reps)])
         stream.synchronize()
         track_stream.synchronize()
+        for st_ in (comm_stream, pred_stream):
+            st_.synchronize()
         if rank == 0:
-            acc = {"track_label_export": 0.0, "broadcast": 0.0, "fuse_decode": 0.0, "predict_draw_merge_resolve": 0.0}
             by = {}
             for name, e in marks:
                 by.setdefault(name, []).append(e)
-            for q in range(reps):
-                acc["track_label_export"] += by["k0"][q].elapsed_time(by["k1"][q])
-                acc["broadcast"] += by["t1"][q].elapsed_time(by["t2"][q])
-                acc["fuse_decode"] += by["t2"][q].elapsed_time(by["t3"][q])
-                acc["predict_draw_merge_resolve"] += by["t3"][q].elapsed_time(by["t4"][q])
-            phases = {k_: round(v / reps * 1e3, 1) for k_, v in acc.items()}
-            phases["work_stream_total"] = round(by["t1"][0].elapsed_time(by["t4"][reps - 1]) / reps * 1e3, 1)
-            phases["unit"] = ("us per step on rank 0 (event pairs, second pass); pipelined: track_label_export runs on the tracker's stream "
-                              "beside the other three" if pipelined else "us per step on rank 0 (event pairs on its stream, second pass)")
+            span = lambda a_, b_: round(sum(by[a_][q].elapsed_time(by[b_][q]) for q in range(reps)) / reps * 1e3, 1)
+            phases = {"track_label_export": span("k0", "k1"), "broadcast": span("t1", "t2"), "fuse": span("w0", "w1"), "decode": span("w1", "w2"),
+                      "predict_draw_merge_resolve": span("p0", "p1") if args.planes_predict else 0.0,
+                      "work_stream_step": round(by["w0"][0].elapsed_time(by["w3"][reps - 1]) / reps * 1e3, 1)}
+            phases["unit"] = ("us per step on rank 0 (event pairs, second pass); pipelined: tracking, broadcast, fusion + decode and the "
+                              "prediction each on a stream of their own, spans overlap" if pipelined else
+                              "us per step on rank 0 (event pairs on its stream, second pass)")
         # the other kernels of the step, one profiled pass each (the library's hook follows one kernel name at a time)
         planes_kernels = []
         ev0 = C.c_double()
@@ -422,9 +454,11 @@ def run_planes(args, env):
         extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
         for kname, nbytes, what in extra:
             kctx = rg_ctx._h if (kname == "k_label_planes_l16" and rank == 0) else ctx._h      # the label kernel runs on the tracker's context
+            if kname.startswith("k_planes_"):
+                kctx = ctx_pred._h                   # the prediction has a context (stream) of its own
             t_ms, cnt = _profile(lib, kctx, kname, lambda: [step() for _ in range(min(reps, 20))])
-            stream.synchronize()
-            track_stream.synchronize()
+            for st_ in (stream, track_stream, comm_stream, pred_stream):
+                st_.synchronize()
             if cnt == 0:
                 continue
             us = max(1e-3, (t_ms / cnt - ev0.value) * 1e3)
@@ -444,8 +478,14 @@ def run_planes(args, env):
         ev_ms = C.c_double()
         lib.rgbdslam_profile_event_overhead(ctx._h, 100, C.byref(ev_ms))
         avg_ms = max(1e-9, tot_ms / max(1, launches) - ev_ms.value)
+        if world > 1:                                # the roofline is that of the first rank that owns planes
+            t_ = torch.tensor([float(cells), avg_ms], dtype=torch.float64, device=env["coll_dev"])
+            dist.broadcast(t_, first_worker)
+            cells, avg_ms = int(t_[0].item()), float(t_[1].item())
         achieved = 54 * cells / (avg_ms * 1e-3) / 1e9
         _barrier(env)
+        if ctx_pred is not ctx:
+            ctx_pred.close()
         if rank != 0:
             ctx.close()
             return None
@@ -459,13 +499,14 @@ def run_planes(args, env):
                                       "(%d bytes), every rank fuses it into and decodes the planes it owns%s" % (pack.nbytes,
                                       ", then draws them into a u64 z-buffer for the frame's view, all-reduce(MIN) of %d bytes, resolve" % (8 * n * m)
                                       if args.planes_predict else ""),
-                          "planes_per_rank": shard.hi - shard.lo, "broadcast_bytes": pack.nbytes, "pack": args.pack,
+                          "planes_per_rank": shard.hi - shard.lo, "tracker_owns_planes": first_worker == 0,
+                          "broadcast_bytes": pack.nbytes, "pack": args.pack,
                           "pipelined": pipelined, "backend": env["backend"],
                           "frames_resident_in_hbm": True},
                "roofline": {"bound": "hbm", "kernel": "k_vertex_from_bump_batch", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                             "algorithmic_bytes_per_launch": 54 * cells, "avg_launch_us": round(avg_ms * 1e3, 2),
-                            "note": "rank 0's share: 54 B per owned Bump cell per launch"},
+                            "note": "rank %d's share: 54 B per owned Bump cell per launch" % first_worker},
                "phases": phases, "planes_kernels": planes_kernels, "cpu_baseline": None,
                "model_checksum": int(chk[0].item()), "cells_fused": int(chk[1].item()),
                "prediction_checksum": int(chk[2].item()) if args.planes_predict else None,
@@ -593,6 +634,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="planes mode: 1 (default) = rank 0 tracks frame f+1 on its own stream beside the fusion / decode / prediction of "
                          "frame f; 0 = one stream, the phases one after the other")
+    ap.add_argument("--tracker-works", default="auto", choices=["auto", "0", "1"],
+                    help="planes mode: does rank 0 (the tracker) own planes too?  auto (default): yes below four ranks, no from four on")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer"],
                     help="rows mode: how the 27 partial sums travel (torch.distributed all-gather, or peer-mapped slots)")
     ap.add_argument("--rows", type=int, default=480)

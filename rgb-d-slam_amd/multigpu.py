@@ -221,10 +221,15 @@ class PlaneShard:
     outputs live here and nowhere else (the table entries of the other planes stay null; the kernels never touch a
     plane outside [plane_lo, plane_hi))."""
 
-    def __init__(self, ctx, params, N, rank, world):
+    def __init__(self, ctx, params, N, rank, world, first_worker=0):
+        """first_worker = 1: rank 0 (the tracking rank) owns no planes -- it still takes part in every collective.  From about four
+        ranks on the tracker's own frame time, not the fusion, bounds the step, and a tracker that also decodes a share of the
+        model is the straggler."""
         self.ctx, self.N = ctx, N
         self.nb = int(params.shape[0])
-        self.lo, self.hi = plane_range(rank, world, self.nb)
+        if first_worker < 0 or first_worker >= world:
+            raise ValueError("first_worker %d with %d ranks" % (first_worker, world))
+        self.lo, self.hi = plane_range(rank - first_worker, world - first_worker, self.nb) if rank >= first_worker else (0, 0)
         k = self.hi - self.lo
         self.param = torch.as_tensor(params, dtype=torch.float32).cuda().contiguous()   # every rank holds all equations (labels)
         self.bump = torch.zeros(k, N, N, 3, dtype=torch.int16, device="cuda")
@@ -249,6 +254,15 @@ class PlaneShard:
 
     def fuse_and_decode(self, pack):
         """Graph::Update (claim + apply) of the owned planes from the broadcast frame, then VertexFromBump of the owned planes."""
+        self.fuse(pack)
+        self.decode()
+
+    def decode(self):
+        if self.hi > self.lo:
+            self.ctx.vertex_from_bump_batch(self.t_vout, self.t_cout, self.t_kout, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
+                                            self.lo, self.hi, self.N, self.N)
+
+    def fuse(self, pack):
         self.stamp += 1
         if self.hi > self.lo:
             if pack.thin:
@@ -261,27 +275,25 @@ class PlaneShard:
                                                  self.t_claim, self.stamp, pack.ptr(pack.off_vmap), pack.ptr(pack.off_rgbd),
                                                  pack.ptr(pack.off_mask), pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m,
                                                  self.lo, self.hi)
-            self.ctx.vertex_from_bump_batch(self.t_vout, self.t_cout, self.t_kout, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
-                                            self.lo, self.hi, self.N, self.N)
 
-
-    def predict(self, pose_w2c16, n, m, min_conf=1):
+    def predict(self, pose_w2c16, n, m, min_conf=1, ctx=None):
         """Prediction of the view `pose_w2c16` (world-to-camera, column-major 4x4) from the planes, partitioned like the
         fusion: this rank draws the planes it owns into its own u64 z-buffer, ONE all-reduce(MIN) merges the ranks'
         buffers (the key is depth bits << 32 | ~triangle id: the nearest surface wins whoever drew it), and the rank
         resolves the pixels its planes won into pred_v / pred_c (the other pixels stay untouched: the ranks' outputs are
         disjoint)."""
+        ctx = ctx or self.ctx                            # (a context on another stream: the prediction beside the decode)
         if getattr(self, "zbuf", None) is None or self.zbuf.shape != (n, m):
             self.zbuf = torch.full((n, m), -1, dtype=torch.int64, device="cuda")       # all ones = empty
             self.pred_v = torch.zeros(n, m, 3, device="cuda")
             self.pred_c = torch.zeros(n, m, 4, device="cuda")
         if self.hi > self.lo:
-            self.ctx.planes_draw(self.zbuf, self.t_bump, self.t_rgb, self.t_mask, self.t_param, self.lo, self.hi, pose_w2c16,
+            ctx.planes_draw(self.zbuf, self.t_bump, self.t_rgb, self.t_mask, self.t_param, self.lo, self.hi, pose_w2c16,
                                  self.N, self.N, n, m, min_conf=min_conf)
         allreduce_min_u64(self.zbuf)
         self.pred_v.zero_(); self.pred_c.zero_()          # pixels other ranks' planes won stay zero here: the outputs are disjoint
         if self.hi > self.lo:
-            self.ctx.planes_resolve(self.zbuf, self.pred_v, self.pred_c, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
+            ctx.planes_resolve(self.zbuf, self.pred_v, self.pred_c, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
                                     self.lo, self.hi, pose_w2c16, self.N, self.N, n, m, reset=False)
         # every rank holds the MERGED buffer: the resolve only clears the pixels this rank's planes won, the rest is cleared here
         self.zbuf.fill_(-1)

@@ -123,6 +123,10 @@ def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():
     # resolve what their planes won -- together exactly the pixels (bits) one rank predicts from all planes
     assert one["predicted_coverage"] > 0.9 and "prediction" in one["metric"]
     assert (one["prediction_checksum"], one["predicted_coverage"]) == (two["prediction_checksum"], two["predicted_coverage"])
+    # the tracking rank without planes of its own (the default from four ranks on): rank 1 owns the whole model
+    solo = _bench(args + ["--tracker-works", "0"], world=2)
+    assert solo["config"]["planes_per_rank"] == 0 and not solo["config"]["tracker_owns_planes"]
+    assert (solo["model_checksum"], solo["cells_fused"], solo["prediction_checksum"]) == (one["model_checksum"], one["cells_fused"], one["prediction_checksum"])
     for o in (one, two):
         assert o["roofline"]["kernel"] == "k_vertex_from_bump_batch" and 0.0 < o["roofline"]["frac"] < 1.0
         assert o["unit"] == "steps/s" and o["value"] > 0
