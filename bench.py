@@ -556,8 +556,11 @@ def run_rows(args, env):
                 raise SystemExit("rgbdslam_debug_set_exchange_delay refused %s" % dl)
         I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
         start = dev(np.concatenate([I, z, I, z]).astype(np.float32))
-        state = start.clone()
-        status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        if args.exchange == "peer_loop":             # the persistent form keeps its state in a device pose block
+            state, status = aligner.pose_block_views()
+        else:
+            state = start.clone()
+            status = torch.zeros(4, dtype=torch.int32, device="cuda")
 
         def step():
             state.copy_(start)
@@ -585,7 +588,8 @@ def run_rows(args, env):
         level_iters = [li & 255, (li >> 8) & 255, (li >> 16) & 255]
         # roofline of this rank's band kernel: 80 B per sampled model pixel of the band per executed iteration
         lib = pkg.load()
-        tot_ms, launches = _profile(lib, ctx._h, "k_icp_iter", lambda: ([step() for _ in range(min(args.steps, 20))], stream.synchronize()))
+        rows_kernel = "k_icp_loop_sharded" if args.exchange == "peer_loop" else "k_icp_iter"
+        tot_ms, launches = _profile(lib, ctx._h, rows_kernel, lambda: ([step() for _ in range(min(args.steps, 20))], stream.synchronize()))
         reps = min(args.steps, 20)
         band_bytes = 0
         for lvl, it in enumerate(level_iters):
@@ -609,10 +613,10 @@ def run_rows(args, env):
                                        % (m, n, world, aligner.exchange),
                            "icp_iterations_per_level": level_iters, "backend": env["backend"], "frames_resident_in_hbm": True,
                            "pose": [float(x) for x in pose[:12].tolist()]},
-                "roofline": {"bound": "hbm", "kernel": "k_icp_iter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "roofline": {"bound": "hbm", "kernel": rows_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                              "algorithmic_bytes_per_frame": band_bytes, "launches_per_frame": round(launches / reps, 1),
-                             "note": "rank 0's band, all its k_icp_iter launches of a frame (incl. the no-op launches after convergence)"},
+                             "note": "rank 0's band, all its %s launches of a frame%s" % (rows_kernel, "" if args.exchange == "peer_loop" else " (incl. the no-op launches after convergence)")},
                 "cpu_baseline": None}
 
 
@@ -636,8 +640,10 @@ def main():
                          "frame f; 0 = one stream, the phases one after the other")
     ap.add_argument("--tracker-works", default="auto", choices=["auto", "0", "1"],
                     help="planes mode: does rank 0 (the tracker) own planes too?  auto (default): yes below four ranks, no from four on")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer"],
-                    help="rows mode: how the 27 partial sums travel (torch.distributed all-gather, or peer-mapped slots)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer", "peer_loop"],
+                    help="rows mode: how the 27 partial sums travel: allgather = torch.distributed all-gather between three launches per "
+                         "iteration; peer = peer-mapped slots written from inside ONE launch per iteration; peer_loop = the same exchange "
+                         "inside ONE persistent launch per alignment (needs the GPU to itself: not for ranks sharing a card)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--kernel", default="k_icp_iter", help="kernel whose roofline is reported")

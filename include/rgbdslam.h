@@ -194,6 +194,7 @@ int rgbdslam_align_band_exchange(rgbdslam_ctx *ctx, const rgbdslam_icp_params *p
                                  int lvl, int iter, int block_row_lo, int block_row_hi, const float *pose_state_dev,
                                  float *trace_dev);
 
+
 /* ---- fused frame pipeline ------------------------------------------------------------------
  * One entry point per METHOD of the reference's L3/L4 classes instead of one per operator; same
  * per-pixel arithmetic (results are bit-identical to the per-operator entry points).  The tracker
@@ -223,6 +224,16 @@ int rgbdslam_track_frame(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, cons
                          const float *Gy, size_t gy_pitch, const float *VMap_prev,
                          const float *NMap_prev, const float *RGB_prev, int n_row, int m_col,
                          rgbdslam_pose_block *pose_block_dev, float *history_dev, int frame_index);
+/* The whole row-sharded Gauss-Newton loop of a frame in ONE persistent launch per rank, the exchange inside it: the sharded
+ * counterpart of rgbdslam_track_frame with rgbdslam_set_icp_loop (no reference counterpart; RG::AlignFrameGaussNewton,
+ * RG.cpp:797-932, for the loop it shards).  band_lo3 / band_hi3 [lvl] = this rank's block rows of level lvl (non-empty at
+ * every level); poses stay bit-identical across ranks and to the multi-launch peer form.  RGBDSLAM_E_STATE without
+ * rgbdslam_set_icp_loop or a connected exchange; at most 15 Gauss-Newton steps per frame (sum of max_iter + 2). */
+int rgbdslam_track_frame_sharded(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap, const float *NMap,
+                                 const float *RGB, const float *Gx, size_t gx_pitch, const float *Gy, size_t gy_pitch,
+                                 const float *VMap_prev, const float *NMap_prev, const float *RGB_prev, int n_row, int m_col,
+                                 rgbdslam_pose_block *pose_block_dev, float *history_dev, int frame_index,
+                                 const int *band_lo3, const int *band_hi3);
 /* PredictedFrame::Cpy + InitMask (Frame.cpp:335-370).  Runs if force != 0 or the block says lost. */
 int rgbdslam_model_reseed(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, int force,
                           const float *frame_VMap, const float *frame_NMap, const float *frame_RGB,

@@ -55,8 +55,9 @@ struct rgbdslam_ctx {
     // row-sharded ICP: peer-mapped exchange blocks (rgbdslam_exchange_*), slot r of every block = rank r's line of sums
     unsigned int *xchg_peer[8];    // [xchg_rank] = this rank's own block; the others are IPC mappings of the peers' blocks
     int xchg_world, xchg_rank;
-    unsigned int xchg_seq;         // advances once per exchanged iteration, in lockstep on every rank
+    unsigned int xchg_seq;         // advances once per exchanging LAUNCH (16 tags, one slot set each), in lockstep on every rank
     int xchg_delay_ticks;          // rgbdslam_debug_set_exchange_delay (test hook)
+    unsigned int **xchg_tab_dev;   // device copy of xchg_peer (the kernels read the block addresses from it)
     // rgbdslam_planes_draw: [0] / [32] the two tile counters (call parity), from word 64 one stamp word per tile, then the queue
     uint32_t *pd_scratch; size_t pd_cap; uint32_t pd_stamp;
     unsigned long long *noalloc_zbuf;   // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc

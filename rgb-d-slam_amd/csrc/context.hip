@@ -24,7 +24,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     for (int k = 0; k < RGBDSLAM_COMPAT_MAX_PLANES; k++) c->claim_slab[k] = nullptr;
     c->claim_tab_dev = nullptr; c->claim_cells = 0; c->claim_stamp = 0; c->label_swap = nullptr; c->label_swap_px = 0; c->compat_counter = nullptr;
     for (int k = 0; k < 8; k++) c->xchg_peer[k] = nullptr;
-    c->xchg_world = 0; c->xchg_rank = 0; c->xchg_seq = 0; c->xchg_delay_ticks = 0;
+    c->xchg_world = 0; c->xchg_rank = 0; c->xchg_seq = 0; c->xchg_delay_ticks = 0; c->xchg_tab_dev = nullptr;
     c->bil_lut = nullptr; c->bil_sigma_color = -1.0;
     c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_launches = 0; c->prof_in_group = false;
     // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc (predict.hip), resolved here so that

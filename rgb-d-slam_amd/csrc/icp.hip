@@ -262,16 +262,21 @@ __device__ __forceinline__ float fold27(const float *v, int lane, float *tr) {
 // its own block carry this iteration's sequence.  Line = four 32-byte sectors of 7 payload words + 1 tag word, tag =
 // seq ^ xor(payload words of the sector): a sector is accepted only when tag ^ xor(payload) == seq, so neither a stale nor
 // a torn sector (whatever granularity the fabric writes at) can pass for this iteration's.
-// The slots are DOUBLE-BUFFERED by the parity of the sequence: a rank that has gathered iteration s may publish s + 1 at once,
-// while a slower peer is still polling for the lines of s -- with one slot per rank that store would overwrite the line the
-// slow peer has not seen yet (with three or more ranks: C's line reaches A before B's does, A runs ahead), and the slow rank
-// would wait for the full timeout and lose the frame.  With two slots a rank overwrites its line of s only when it publishes
-// s + 2, i.e. after it has gathered every peer's line of s + 1, and a peer publishes s + 1 only after it has consumed s.
+// The slots are MULTI-BUFFERED: a rank that has gathered exchange e may publish e + 1 at once, while a slower peer is still
+// polling for the lines of e -- with one slot per rank that store would overwrite the line the slow peer has not seen yet
+// (with three or more ranks: C's line reaches A before B's does, A runs ahead), and the slow rank would wait for the full
+// timeout and lose the frame.  Rule: a rank overwrites a line only two or more exchanges after it wrote it (it publishes e + 2
+// after it has gathered every peer's line of e + 1, and a peer publishes e + 1 only after it has consumed e).  A launch owns
+// 16 slots per rank -- slot q = 1..15 for its q-th step (the persistent loop may jump over steps, so consecutive EXECUTED
+// steps differ by 1..15 slots, never 0; the multi-launch form uses q = 1) -- and consecutive launches alternate between two such
+// sets (parity), so the first exchange of a launch never lands on the last one of the launch before.
 #define ICP_XCHG_MAX_WORLD 8
-#define ICP_XCHG_SLOT_WORDS(rank, seq) (32u * ((unsigned)(rank) + ICP_XCHG_MAX_WORLD * ((seq) & 1u)))
-struct IcpXchg { unsigned int *peer[ICP_XCHG_MAX_WORLD]; int world, rank; unsigned int seq; int delay_ticks; };   // delay_ticks: test hook, see rgbdslam_debug_set_exchange_delay
+#define ICP_XCHG_STEPS 16                            // slots per rank and launch parity (steps 1..15 of a launch)
+#define ICP_XCHG_LINE_WORDS(rank, q, parity) (32u * ((unsigned)(rank) + ICP_XCHG_MAX_WORLD * ((unsigned)(q) + ICP_XCHG_STEPS * (unsigned)(parity))))
+// tab: DEVICE table of the world block addresses ([rank] = this rank's own); tag = tag_base + q is unique per exchange
+struct IcpXchg { unsigned int *const *tab; int world, rank; unsigned int tag_base; int parity; int delay_ticks; };   // delay_ticks: test hook, see rgbdslam_debug_set_exchange_delay
 struct IcpIterArgs {
-    int nx_lvl, nx_rows, nx_cols;                    // persistent loop: the level after this one (-1: none), its block grid
+    int nx_lvl, nx_rows, nx_cols, nx_br_lo;          // persistent loop: the level after this one (-1: none), its block grid (band)
     IcpXchg xchg;                                    // world == 0: no exchange
     const float *intr, *R, *t;                       // device scalars (user buffers or &IcpState fields)
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
@@ -370,7 +375,8 @@ __device__ __forceinline__ void icp_state_copy(IcpState *d, const IcpState *s) {
     d->cvg = s->cvg; d->fail = s->fail; d->iters = s->iters; d->lvl_iters = s->lvl_iters;
 }
 
-template <bool LOOP>
+// XCHG: the row-sharded form -- the tail exchanges its band's 27 sums with the peers' before the solve
+template <bool LOOP, bool XCHG>
 __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpShared &S, IcpLoopCtl lc, const int tid, const int t,
                                               IcpModelCache &mc) {
     float (&part)[2][ICP_MAX_WAVES][27] = S.part;
@@ -498,7 +504,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         for (int h = 0; h < 2; h++) {
             const int kk = wv + h * ICP_CHAIN_WAVES;
             const int blk = tc + ICP_CHAINS * kk;
-            const int i = (blk % nx_rows) * 8 + (lane >> 3), j = (blk / nx_rows) * 8 + (lane & 7);
+            const int i = ((XCHG ? a.nx_br_lo : 0) + blk % nx_rows) * 8 + (lane >> 3), j = (blk / nx_rows) * 8 + (lane & 7);
             in[h] = kk < len_n && i * nfact < a.n && j * nfact < a.m;
             id[h] = in[h] ? (unsigned int)(i * nfact) * (unsigned int)a.m + (unsigned int)(j * nfact) : 0u;
         }
@@ -646,23 +652,27 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     }
     long long ts4 = a.timing ? wall_clock64() : 0;
     __syncthreads();
-    if (!LOOP && a.xchg.world > 0) {                  // uniform over the grid; the tail is the only workgroup still here
+    if (XCHG && a.xchg.world > 0) {                   // uniform over the grid; the tail is the only workgroup still here
         if (wave == 0) {
+            const unsigned int q = LOOP ? (unsigned int)lc.step + 1u : 1u;         // slot of this exchange within its launch
+            const unsigned int tag = a.xchg.tag_base + q;
             // publish: slot l of the line = term l - l/8 (as in the chain lines), tag words in slots 7, 15, 23, 31
             const int k = lane - (lane >> 3);
             unsigned int word = ((lane & 7) != 7 && k < 27 && lane < 32) ? __float_as_uint(fin[k]) : 0u;
             unsigned int x = word;
             x ^= (unsigned int)__shfl_xor((int)x, 1); x ^= (unsigned int)__shfl_xor((int)x, 2); x ^= (unsigned int)__shfl_xor((int)x, 4);
-            if ((lane & 7) == 7) word = a.xchg.seq ^ x;
-            for (int p = 0; p < a.xchg.world; p++)
+            if ((lane & 7) == 7) word = tag ^ x;
+            for (int p = 0; p < a.xchg.world; p++) {
+                unsigned int *peer = a.xchg.tab[p];
                 if (lane < 32)
-                    __hip_atomic_store(a.xchg.peer[p] + ICP_XCHG_SLOT_WORDS(a.xchg.rank, a.xchg.seq) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(peer + ICP_XCHG_LINE_WORDS(a.xchg.rank, q, a.xchg.parity) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (a.xchg.delay_ticks > 0) {            // test hook: this rank falls behind between its publication and its first poll
                 const long long t_d = wall_clock64();
                 while (wall_clock64() - t_d < (long long)a.xchg.delay_ticks) __builtin_amdgcn_s_sleep(32);
             }
             // gather: lane reads word lane % 32 of lines 2i + lane / 32 of the own block
-            const unsigned int *mine = a.xchg.peer[a.xchg.rank] + ICP_XCHG_SLOT_WORDS(0, a.xchg.seq);
+            const unsigned int *mine = a.xchg.tab[a.xchg.rank] + ICP_XCHG_LINE_WORDS(0, q, a.xchg.parity);
             unsigned int v[ICP_XCHG_MAX_WORLD / 2];
             const long long t_poll = wall_clock64();
             bool gave_up = false;
@@ -675,7 +685,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
                     v[i] = live ? __hip_atomic_load(mine + 32 * line + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
                     unsigned int y = v[i];
                     y ^= (unsigned int)__shfl_xor((int)y, 1); y ^= (unsigned int)__shfl_xor((int)y, 2); y ^= (unsigned int)__shfl_xor((int)y, 4);
-                    bad |= live && y != a.xchg.seq;
+                    bad |= live && y != tag;
                 }
                 if (__ballot(bad) == 0ull) break;
                 if (wall_clock64() - t_poll > (long long)a.timeout_ticks) { gave_up = true; break; }   // 50 ms: a peer never published
@@ -715,7 +725,7 @@ __global__ __launch_bounds__(64 * ICP_MAX_WAVES)
 void k_icp_iter(IcpIterArgs a) {
     ICP_SHARED_DECL(S);
     IcpModelCache mc;
-    icp_iter_body<false>(a, S, IcpLoopCtl{nullptr, 0u, 0, 0, 0, 0}, (int)threadIdx.x, (int)blockIdx.x, mc);
+    icp_iter_body<false, true>(a, S, IcpLoopCtl{nullptr, 0u, 0, 0, 0, 0}, (int)threadIdx.x, (int)blockIdx.x, mc);
 }
 
 // ---- persistent coarse-to-fine loop: ALL iterations of a frame in one launch -----------------------
@@ -729,7 +739,7 @@ void k_icp_iter(IcpIterArgs a) {
 // steps are numbered through the levels, coarse to fine; level k owns [start, start + max_iter + 2)
 // packed (two scalar registers per level instead of five -- the loop is short of them): w0 = start | max_iter << 16 | lvl << 28,
 // w1 = grid_rows | grid_cols << 16
-struct IcpLoopLevel { unsigned int w0, w1; };
+struct IcpLoopLevel { unsigned int w0, w1, w2; };    // w2 (row-sharded form only) = first block row of the band | rows of the band << 16
 #define ICP_LV_UNUSED 0xffffu
 // The argument block is kept small on purpose: every field stays in a scalar register for the whole
 // loop, and what does not fit is spilled into vector registers and scratch memory.  The five ICP work
@@ -756,13 +766,15 @@ struct IcpLoopArgs {
     int nsteps;
     unsigned int epoch_base;
     int timeout_ticks;
+    // row-sharded form (k_icp_loop<.., true>): the peers' exchange blocks and this launch's tags / slot set
+    unsigned int *const *xtab; unsigned int xtag_base; int xworld, xrank, xparity, xdelay;
 #ifdef ICP_LOOP_TIMING
     long long *timing;                               // debug build only: 8 time stamps per step (rgbdslam_debug_icp_timing)
 #endif
 };
 
 // CHECK = rgbdslam_set_icp_line_check, a template parameter so that the default kernel carries none of the checking code
-template <bool CHECK>
+template <bool CHECK, bool XCHG = false>
 __global__ __launch_bounds__(64 * ICP_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(3)))
 void k_icp_loop(IcpLoopArgs L) {
     ICP_SHARED_DECL(S);
@@ -787,10 +799,19 @@ void k_icp_loop(IcpLoopArgs L) {
         const unsigned int lw0 = in2 ? L.lv[2].w0 : (in1 ? L.lv[1].w0 : L.lv[0].w0);
         const unsigned int lw1 = in2 ? L.lv[2].w1 : (in1 ? L.lv[1].w1 : L.lv[0].w1);
         const int grid_rows = (int)(lw1 & 0xffffu), grid_cols = (int)(lw1 >> 16);
-        const int nchain = min(grid_rows * grid_cols, ICP_CHAINS);
+        int br_lo = 0, rows_local = grid_rows;
+        if (XCHG) {                                   // this rank's band of the level's block rows
+            const unsigned int lw2 = in2 ? L.lv[2].w2 : (in1 ? L.lv[1].w2 : L.lv[0].w2);
+            br_lo = (int)(lw2 & 0xffffu); rows_local = (int)(lw2 >> 16);
+        }
+        const int nchain = min(rows_local * grid_cols, ICP_CHAINS);
         if (t < min(nchain, ICP_WGS)) {
             IcpIterArgs a;
-            a.xchg.world = 0; a.fault = (int *)(L.block + ICP_OFF_EPOCH + 128);
+            if (XCHG) {
+                a.xchg.tab = L.xtab; a.xchg.world = L.xworld; a.xchg.rank = L.xrank; a.xchg.tag_base = L.xtag_base;
+                a.xchg.parity = L.xparity; a.xchg.delay_ticks = L.xdelay;
+            } else a.xchg.world = 0;
+            a.fault = (int *)(L.block + ICP_OFF_EPOCH + 128);
             a.line_check = CHECK; a.rejections = (unsigned int *)(L.block + ICP_OFF_EPOCH) + ICP_OFF_REJECT_WORD;
             a.timeout_ticks = L.timeout_ticks;
             a.intr = nullptr; a.R = nullptr; a.t = nullptr;
@@ -803,10 +824,14 @@ void k_icp_loop(IcpLoopArgs L) {
                 const unsigned int nw0 = in2 ? ICP_LV_UNUSED : (in1 ? L.lv[2].w0 : L.lv[1].w0);
                 const unsigned int nw1 = in1 ? L.lv[2].w1 : L.lv[1].w1;
                 a.nx_lvl = (nw0 & 0xffffu) == ICP_LV_UNUSED ? -1 : (int)(nw0 >> 28);
-                a.nx_rows = (int)(nw1 & 0xffffu); a.nx_cols = (int)(nw1 >> 16);
+                a.nx_rows = (int)(nw1 & 0xffffu); a.nx_cols = (int)(nw1 >> 16); a.nx_br_lo = 0;
+                if (XCHG) {
+                    const unsigned int nw2 = in1 ? L.lv[2].w2 : L.lv[1].w2;
+                    a.nx_br_lo = (int)(nw2 & 0xffffu); a.nx_rows = (int)(nw2 >> 16);
+                }
             }
             a.fact = 1 << a.lvl; a.grid_rows = grid_rows; a.grid_cols = grid_cols;
-            a.br_lo = 0; a.rows_local = grid_rows; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
+            a.br_lo = br_lo; a.rows_local = rows_local; a.nchain = nchain; a.nwaves = ICP_MAX_WAVES;
             a.chains = (float *)(L.block + ICP_OFF_CHAINS);
             a.sums = (float *)(L.block + ICP_OFF_OUT); a.corr = nullptr; a.seq = L.epoch_base + (unsigned int)s + 1u;
             a.state = (IcpState *)(L.block + ICP_OFF_STATE); a.pose_state = L.pb->pose_state;
@@ -820,7 +845,7 @@ void k_icp_loop(IcpLoopArgs L) {
             a.first_launch = (s == 0); a.final_launch = 0;
             a.pose_state_rw = L.pb->pose_state; a.status = L.pb->status; a.pb = L.pb; a.history = L.history;
             a.frame_index = L.frame_index;
-            icp_iter_body<true>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps, CHECK}, tid, t, mc);
+            icp_iter_body<true, XCHG>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps, CHECK}, tid, t, mc);
         }
         __syncthreads();                               // every thread is done with S
         if (tid < 64) {                                // wave 0 polls the published line, one word per lane
@@ -1375,9 +1400,11 @@ extern "C" int rgbdslam_set_icp_loop(rgbdslam_ctx *ctx, int on) {
     // The occupancy query packs waves freely over the four SIMDs of a CU; the dispatcher deals a workgroup's waves
     // to the SIMDs starting from the first one (measured with 5-wave workgroups: at 144 registers = 3 waves per SIMD
     // only ONE was resident per CU and the loop starved), so SIMD 0 must have room for every workgroup's share.
-    hipFuncAttributes fa;
+    hipFuncAttributes fa, fx;
     HIP_TRY(hipFuncGetAttributes(&fa, (const void *)k_icp_loop<true>));
-    const int regs = ((fa.numRegs > 0 ? fa.numRegs : 512) + 7) & ~7;
+    HIP_TRY(hipFuncGetAttributes(&fx, (const void *)k_icp_loop<false, true>));      // the row-sharded instance
+    const int nregs = fa.numRegs > fx.numRegs ? fa.numRegs : fx.numRegs;
+    const int regs = ((nregs > 0 ? nregs : 512) + 7) & ~7;
     const int waves_per_simd = 512 / regs < 8 ? 512 / regs : 8;
     const int wgs_per_cu = (ICP_WGS + cus - 1) / cus;
     if (wgs_per_cu * ((ICP_MAX_WAVES + 3) / 4) > waves_per_simd) return RGBDSLAM_E_STATE;
@@ -1502,7 +1529,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     if (br_hi <= br_lo) return RGBDSLAM_E_ARG;
     if (!ctx->buf_dev) return RGBDSLAM_E_STATE;
     IcpIterArgs a;
-    a.nx_lvl = -1; a.nx_rows = 1; a.nx_cols = 1;
+    a.nx_lvl = -1; a.nx_rows = 1; a.nx_cols = 1; a.nx_br_lo = 0;
     if (xchg) a.xchg = *xchg; else a.xchg.world = 0;
     a.fault = ctx->icp_epoch_dev ? (int *)(ctx->icp_epoch_dev + 32) : nullptr;
     a.line_check = ctx->icp_line_check; a.rejections = ctx->icp_epoch_dev ? ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD : nullptr;
@@ -1558,6 +1585,7 @@ extern "C" int rgbdslam_estimate_system_gauss_newton(rgbdslam_ctx *ctx, const fl
     return 0;
 }
 
+static int xchg_next(rgbdslam_ctx *ctx, IcpXchg *x);
 static int check_align_args(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, int n, int m, size_t gxp, size_t gyp) {
     if (n <= 0 || m <= 0 || prm->lvl < 1 || prm->lvl > 3 || gxp < 4 * (size_t)m || gyp < 4 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib || !ctx->icp_state) return RGBDSLAM_E_STATE;
@@ -1568,7 +1596,7 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
                       const float *RGB, const float *Gx, size_t gxp, const float *Gy, size_t gyp, const float *VMap_prev,
                       const float *NMap_prev, const float *RGB_prev, int n, int m, float *pose_state_dev,
                       int32_t *status_dev, float *trace_dev, rgbdslam_pose_block *pose_block, float *history,
-                      int frame_index) {
+                      int frame_index, const int *band_lo = nullptr, const int *band_hi = nullptr) {
     if (!ctx || !prm || !VMap || !NMap || !RGB || !Gx || !Gy || !VMap_prev || !NMap_prev || !RGB_prev ||
         !pose_state_dev || !status_dev)
         return RGBDSLAM_E_ARG;
@@ -1581,6 +1609,8 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
     IcpEndArgs end = {pose_state_dev, status_dev, pose_block, history, frame_index};
     if (!ride) KLAUNCH(ctx, k_icp_begin, dim3(1), dim3(64), st, pose_state_dev, ctx->calib, status_dev);
     int fact = 1 << (prm->lvl - 1);                            // RG.cpp:832
+    const bool sharded = band_lo != nullptr;
+    if (sharded && !(ride && ctx->icp_loop && ctx->icp_block)) return RGBDSLAM_E_STATE;   // the sharded form IS the persistent loop
     if (ride && ctx->icp_loop && ctx->icp_block && !trace_dev && pose_state_dev == pose_block->pose_state &&
         status_dev == pose_block->status) {
         IcpLoopArgs L;
@@ -1592,8 +1622,15 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
             if (gr > 0xffff || gc > 0xffff || lvl > 3) return RGBDSLAM_E_ARG;
             L.lv[nl].w0 = (unsigned int)ns | ((unsigned int)prm->max_iter[lvl] << 16) | ((unsigned int)lvl << 28);
             L.lv[nl].w1 = (unsigned int)gr | ((unsigned int)gc << 16);
+            L.lv[nl].w2 = (unsigned int)gr << 16;
+            if (sharded) {                                     // every rank needs a tail at every level: no empty bands
+                const int lo = band_lo[lvl] < 0 ? 0 : band_lo[lvl], hi = band_hi[lvl] > gr ? gr : band_hi[lvl];
+                if (hi <= lo) return RGBDSLAM_E_ARG;
+                L.lv[nl].w2 = (unsigned int)lo | ((unsigned int)(hi - lo) << 16);
+            }
             ns += prm->max_iter[lvl] + 2;                      // iter = 0 .. max_iter+1 (RG.cpp:889)
         }
+        if (sharded && ns > ICP_XCHG_STEPS - 1) return RGBDSLAM_E_LIMIT;   // one exchange slot per step of a launch
         for (int k = nl; k < 3; k++) { L.lv[k] = L.lv[0]; L.lv[k].w0 |= ICP_LV_UNUSED; }
         if (!icp_offsets_fit(n, m, gxp, gyp)) return RGBDSLAM_E_ARG;
         L.VMap = VMap; L.NMap = NMap; L.RGB = RGB; L.Gx = Gx; L.Gy = Gy; L.gxp = (unsigned int)gxp; L.gyp = (unsigned int)gyp;
@@ -1610,7 +1647,16 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
 #ifdef ICP_LOOP_TIMING
         L.timing = ctx->icp_timing_dev;
 #endif
-        if (ctx->icp_line_check) KLAUNCH(ctx, k_icp_loop<true>, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
+        L.xtab = nullptr; L.xtag_base = 0; L.xworld = 0; L.xrank = 0; L.xparity = 0; L.xdelay = 0;
+        if (sharded) {
+            IcpXchg x;
+            rc = xchg_next(ctx, &x);
+            if (rc) return rc;
+            L.xtab = x.tab; L.xtag_base = x.tag_base; L.xworld = x.world; L.xrank = x.rank; L.xparity = x.parity; L.xdelay = x.delay_ticks;
+            void (*const k_icp_loop_sharded)(IcpLoopArgs) = k_icp_loop<false, true>;      // (the profiling hook's name for it)
+            KLAUNCH(ctx, k_icp_loop_sharded, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
+        }
+        else if (ctx->icp_line_check) KLAUNCH(ctx, k_icp_loop<true>, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
         else KLAUNCH(ctx, k_icp_loop<false>, dim3(ICP_WGS), dim3(64 * ICP_MAX_WAVES), L);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -1650,6 +1696,20 @@ extern "C" int rgbdslam_track_frame(rgbdslam_ctx *ctx, const rgbdslam_icp_params
     if (!pb || frame_index < 0) return RGBDSLAM_E_ARG;
     return align_impl(ctx, prm, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev, NMap_prev, RGB_prev, n, m, pb->pose_state, pb->status,
                       nullptr, pb, history_dev, frame_index);
+}
+
+// Row-sharded form of rgbdslam_track_frame, the whole coarse-to-fine loop in ONE persistent launch per rank with the 27-float
+// exchange inside it (RG.cpp:837-904 is one dependent chain per frame, and the multi-launch sharded form paid
+// the twelve launch boundaries the single-GPU path had got rid of).  band_lo / band_hi [lvl]: this rank's block rows of
+// level lvl's grid.  Needs rgbdslam_set_icp_loop (the GPU to itself) and a connected exchange; every rank makes the same calls.
+extern "C" int rgbdslam_track_frame_sharded(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const float *VMap, const float *NMap,
+                                            const float *RGB, const float *Gx, size_t gxp, const float *Gy, size_t gyp,
+                                            const float *VMap_prev, const float *NMap_prev, const float *RGB_prev, int n, int m,
+                                            rgbdslam_pose_block *pb, float *history_dev, int frame_index, const int *band_lo3,
+                                            const int *band_hi3) {
+    if (!pb || frame_index < 0 || !band_lo3 || !band_hi3) return RGBDSLAM_E_ARG;
+    return align_impl(ctx, prm, VMap, NMap, RGB, Gx, gxp, Gy, gyp, VMap_prev, NMap_prev, RGB_prev, n, m, pb->pose_state, pb->status,
+                      nullptr, pb, history_dev, frame_index, band_lo3, band_hi3);
 }
 
 // ---- row-sharded Gauss-Newton loop (BASELINE configs[3]): the caller interleaves a
@@ -1699,7 +1759,7 @@ extern "C" int rgbdslam_align_end(rgbdslam_ctx *ctx, float *pose_state_dev, int3
 }
 
 // ---- peer-mapped exchange of the 27 band sums (row-sharded ICP over several GPUs; no reference counterpart) ----------
-#define XCHG_BLOCK_BYTES (2 * ICP_XCHG_MAX_WORLD * 128)   // two slots per rank (parity of the sequence)
+#define XCHG_BLOCK_BYTES (2 * ICP_XCHG_STEPS * ICP_XCHG_MAX_WORLD * 128)   // 32 slots per rank: 16 steps x 2 launch parities = 32 KB
 static_assert(sizeof(hipIpcMemHandle_t) <= RGBDSLAM_EXCHANGE_HANDLE_BYTES, "IPC handle size");
 
 extern "C" int rgbdslam_exchange_create(rgbdslam_ctx *ctx, int world, int rank, void *handle_out) {
@@ -1727,6 +1787,16 @@ extern "C" int rgbdslam_exchange_create(rgbdslam_ctx *ctx, int world, int rank, 
     return 0;
 }
 
+// the exchange descriptor of the next launch: every launch (or multi-launch iteration) owns 16 tags and one of the two slot sets
+static int xchg_next(rgbdslam_ctx *ctx, IcpXchg *x) {
+    if (!ctx->xchg_world) return RGBDSLAM_E_STATE;
+    if (!ctx->xchg_tab_dev) return RGBDSLAM_E_STATE;          // rgbdslam_exchange_connect has not run
+    const unsigned int launch = ++ctx->xchg_seq;
+    x->tab = (unsigned int *const *)ctx->xchg_tab_dev; x->world = ctx->xchg_world; x->rank = ctx->xchg_rank;
+    x->tag_base = launch * (unsigned int)ICP_XCHG_STEPS; x->parity = (int)(launch & 1u); x->delay_ticks = ctx->xchg_delay_ticks;
+    return 0;
+}
+
 // all_handles: world x RGBDSLAM_EXCHANGE_HANDLE_BYTES, entry r = what rank r's rgbdslam_exchange_create returned
 extern "C" int rgbdslam_exchange_connect(rgbdslam_ctx *ctx, const void *all_handles) {
     if (!ctx) return RGBDSLAM_E_ARG;
@@ -1741,6 +1811,10 @@ extern "C" int rgbdslam_exchange_connect(rgbdslam_ctx *ctx, const void *all_hand
         HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
         ctx->xchg_peer[r] = (unsigned int *)p;
     }
+    // the kernels read the block addresses from a device table (eight pointers as kernel arguments would cost the
+    // persistent loop sixteen scalar registers it does not have)
+    if (!ctx->xchg_tab_dev) HIP_TRY(hipMalloc((void **)&ctx->xchg_tab_dev, sizeof(void *) * ICP_XCHG_MAX_WORLD));
+    HIP_TRY(hipMemcpy(ctx->xchg_tab_dev, ctx->xchg_peer, sizeof(void *) * ICP_XCHG_MAX_WORLD, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1755,6 +1829,7 @@ extern "C" int rgbdslam_exchange_destroy(rgbdslam_ctx *ctx) {
         else (void)hipIpcCloseMemHandle(ctx->xchg_peer[r]);
         ctx->xchg_peer[r] = nullptr;
     }
+    if (ctx->xchg_tab_dev) { (void)hipFree(ctx->xchg_tab_dev); ctx->xchg_tab_dev = nullptr; }
     ctx->xchg_world = 0;
     return 0;
 }
@@ -1773,12 +1848,9 @@ extern "C" int rgbdslam_align_band_exchange(rgbdslam_ctx *ctx, const rgbdslam_ic
     int rc = check_align_args(ctx, prm, n, m, gxp, gyp);
     if (rc) return rc;
     if (lvl < 0 || lvl >= prm->lvl || iter < 0 || block_row_hi <= block_row_lo) return RGBDSLAM_E_ARG;
-    if (!ctx->xchg_world) return RGBDSLAM_E_STATE;
     IcpXchg x;
-    for (int r = 0; r < ICP_XCHG_MAX_WORLD; r++) x.peer[r] = r < ctx->xchg_world ? ctx->xchg_peer[r] : nullptr;
-    for (int r = 0; r < ctx->xchg_world; r++)
-        if (!x.peer[r]) return RGBDSLAM_E_STATE;              // rgbdslam_exchange_connect has not run
-    x.world = ctx->xchg_world; x.rank = ctx->xchg_rank; x.seq = ++ctx->xchg_seq; x.delay_ticks = ctx->xchg_delay_ticks;
+    rc = xchg_next(ctx, &x);
+    if (rc) return rc;
     IcpState *st = ctx->icp_state;
     IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
     return launch_iter(ctx, st->intr, st->Rcurr, st->tcurr, mp, prm->distThres, prm->angleThres, n, m, 1 << lvl, block_row_lo,

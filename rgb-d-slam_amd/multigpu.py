@@ -80,8 +80,19 @@ class ShardedAligner:
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.sums = torch.zeros(27, dtype=torch.float32, device="cuda")
         self.gathered = torch.zeros(self.world, 27, dtype=torch.float32, device="cuda")
-        if exchange == "peer":
+        if exchange in ("peer", "peer_loop"):
             self._connect_peers()
+        if exchange == "peer_loop":
+            # ONE persistent launch per alignment and rank (rgbdslam_track_frame_sharded): the state lives in a device-resident
+            # rgbdslam_pose_block (pose_state 24 f32, status 4 i32, three 4x4 poses); align() takes views of it
+            ctx.set_icp_loop(True)                   # raises unless this process has the GPU to itself
+            self.pb = torch.zeros(76, dtype=torch.float32, device="cuda")
+            self.history = torch.zeros(16, dtype=torch.float32, device="cuda")
+            self.bands = {}
+
+    def pose_block_views(self):
+        """(pose_state [24] f32, status [4] i32): views of the device pose block of the peer_loop form"""
+        return self.pb[:24], self.pb[24:28].view(torch.int32)
 
     HANDLE_BYTES = 64   # RGBDSLAM_EXCHANGE_HANDLE_BYTES
 
@@ -116,6 +127,20 @@ class ShardedAligner:
         lib, h, prm, n, m = self.ctx.lib, self.ctx._h, self.prm, self.n, self.m
         pitch = pitch or 4 * m
         p = lambda t: C.c_void_p(t.data_ptr())
+        if self.exchange == "peer_loop":
+            if pose_state.data_ptr() != self.pb.data_ptr() or status.data_ptr() != self.pb.data_ptr() + 96:
+                raise ValueError("peer_loop: pose_state / status must be the views of pose_block_views()")
+            lo3, hi3 = (C.c_int * 3)(), (C.c_int * 3)()
+            for lvl in range(prm.lvl):
+                lo3[lvl], hi3[lvl] = band_rows(self.rank, self.world, self._div_up(n // (1 << lvl), 8))
+                if hi3[lvl] <= lo3[lvl]:
+                    raise RuntimeError("peer exchange needs a non-empty band on every rank (level %d)" % lvl)
+            rc = lib.rgbdslam_track_frame_sharded(h, C.byref(prm), p(vmap), p(nmap), p(rgb), p(gx), C.c_size_t(pitch), p(gy),
+                                                  C.c_size_t(pitch), p(vprev), p(nprev), p(rgbd_prev), n, m, p(self.pb),
+                                                  p(self.history), 0, lo3, hi3)
+            if rc:
+                raise RuntimeError("track_frame_sharded failed: %d" % rc)
+            return
         rc = lib.rgbdslam_align_begin(h, p(pose_state), p(status))
         if rc:
             raise RuntimeError("align_begin failed: %d" % rc)

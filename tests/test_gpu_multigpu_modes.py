@@ -60,14 +60,17 @@ def test_peer_exchange_equals_allgather_single_rank(pkg, synth, orc):
     _, gx, gy = orc.intensity_sobel(rgb1)
     I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
     poses = {}
-    for mode in ("allgather", "peer"):
+    for mode in ("allgather", "peer", "peer_loop"):
         ctx = pkg.Context(0)
         ctx.set_calibration_matrix(calib)
         ctx.alloc_buffers((n + 7) // 8, (m + 7) // 8)
         al = multigpu.ShardedAligner(ctx, pkg.icp_params(), n, m, 0, 1, exchange=mode)
-        state = dev(np.concatenate([I, z, I, z]).astype(np.float32))
-        status = torch.zeros(4, dtype=torch.int32, device="cuda")
-        for _ in range(2):                              # twice: the sequence words move on, stale lines must not pass
+        if mode == "peer_loop":                         # ONE persistent launch per alignment, the exchange inside it
+            state, status = al.pose_block_views()
+        else:
+            state = dev(np.concatenate([I, z, I, z]).astype(np.float32))
+            status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        for _ in range(3):                              # repeatedly: tags and slot sets move on, stale lines must not pass
             state.copy_(dev(np.concatenate([I, z, I, z]).astype(np.float32)))
             al.align(dev(v1), dev(n1), dev(rgb1), dev(gx), dev(gy), dev(v0), dev(n0), dev(rgbd0), state, status)
         ctx.synchronize()
@@ -75,8 +78,51 @@ def test_peer_exchange_equals_allgather_single_rank(pkg, synth, orc):
         ctx.close()
     assert int(poses["peer"][1][0]) == 1 and int(poses["peer"][1][1]) >= 6
     assert np.array_equal(poses["peer"][0], poses["allgather"][0]) and np.array_equal(poses["peer"][1], poses["allgather"][1])
+    # the persistent form: same pose, same iteration counts (its pose block also carries display()'s "previous := current")
+    assert np.array_equal(poses["peer_loop"][0][:12], poses["peer"][0][:12]) and np.array_equal(poses["peer_loop"][1][:3], poses["peer"][1][:3])
     ok, R, t, _ = orc.align_gauss_newton(orc.icp_params(), calib[:4], v1, n1, rgb1, v0, n0, rgbd0, I, z, I, z)
     assert ok and np.array_equal(poses["peer"][0][:9], R) and np.array_equal(poses["peer"][0][9:12], t)   # one band = the single-GPU sums
+
+
+def test_sharded_persistent_loop_gives_up_cleanly(pkg, synth, orc):
+    """rgbdslam_track_frame_sharded with every device-side wait told to give up at once (rgbdslam_debug_set_icp_timeout(0)): the
+    launch completes, the frame counts as lost and the fault is reported; with the timeout restored the next alignment tracks."""
+    multigpu = importlib.import_module("rgb-d-slam_amd.multigpu")
+    n, m = 120, 160
+    calib = synth.calib_for(n, m)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d0, c0 = synth.render(np.eye(3), np.zeros(3), n, m, calib)
+    R1, t1 = synth.pair_offset_pose()
+    d1, c1 = synth.render(R1, t1, n, m, calib)
+    v0 = orc.vertex_map_kinect(d0, calib); n0 = orc.compute_normal(v0); rgb0 = orc.cpy_char3(c0)
+    v1 = orc.vertex_map_kinect(d1, calib); n1 = orc.compute_normal(v1); rgb1 = orc.cpy_char3(c1)
+    rgbd0 = orc.add_zbuff_off(d0, rgb0, calib)
+    _, gx, gy = orc.intensity_sobel(rgb1)
+    g = [dev(x) for x in (v1, n1, rgb1, gx, gy, v0, n0, rgbd0)]
+    I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+    start = dev(np.concatenate([I, z, I, z]).astype(np.float32))
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_calibration_matrix(calib)
+        ctx.alloc_buffers((n + 7) // 8, (m + 7) // 8)
+        al = multigpu.ShardedAligner(ctx, pkg.icp_params(), n, m, 0, 1, exchange="peer_loop")
+        state, status = al.pose_block_views()
+        ctx.debug_set_icp_timeout(0)
+        state.copy_(start)
+        al.align(*g, state, status)
+        ctx.synchronize()
+        assert int(status[0]) == 0 and ctx.icp_loop_faults() > 0
+        ctx.debug_set_icp_timeout(5000000)
+        ctx.set_icp_loop(True)                          # (a fault switches the mode off)
+        state.copy_(start)
+        al.align(*g, state, status)
+        ctx.synchronize()
+        assert int(status[0]) == 1 and ctx.icp_loop_faults() == 0
+        ok, R, t, _ = orc.align_gauss_newton(orc.icp_params(), calib[:4], v1, n1, rgb1, v0, n0, rgbd0, I, z, I, z)
+        s = state.cpu().numpy()
+        assert ok and np.array_equal(s[:9], R) and np.array_equal(s[9:12], t)
+    finally:
+        ctx.close()
 
 
 def test_rows_mode_two_ranks_on_one_card_peer_and_allgather():
