@@ -545,6 +545,16 @@ class RG:
         _hchk(self.lib.slamhost_rg_get_planes(self._h, C.c_void_p(eq.ctypes.data), C.c_void_p(ce.ctypes.data), cap), "get_planes")
         return eq[:nb.value], ce[:nb.value]
 
+    def reorganize_equa(self):
+        """RG::ReorganizeEqua (D1/RG.cpp:934-1006): drops the planes with at most MIN_SIZE_PLAN labelled pixels in the model
+        frame, renumbers the rest (labels, equations, centres, Bump images).  -> (equations [k,10], centers [k,3])"""
+        import numpy as np
+        nb = C.c_int()
+        _hchk(self.lib.slamhost_rg_reorganize_equa(self._h, C.byref(nb)), "reorganize_equa")
+        eq, ce = np.zeros((max(nb.value, 1), 10), np.float32), np.zeros((max(nb.value, 1), 3), np.float32)
+        _hchk(self.lib.slamhost_rg_get_planes(self._h, C.c_void_p(eq.ctypes.data), C.c_void_p(ce.ctypes.data), max(nb.value, 1)), "get_planes")
+        return eq[:nb.value], ce[:nb.value]
+
     def set_bilateral(self, on):
         """Optional stage of OffLineFrame::LoadFrame, default OFF like in the reference (the call is commented out there,
         D1/Frame.cpp:50-54): cv::bilateralFilter(depth, 5, 100.0, 100.0) before the vertex map is computed."""

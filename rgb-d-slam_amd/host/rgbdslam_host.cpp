@@ -1,5 +1,6 @@
 // rgbdslam_host.cpp -- C++ host mirror of the reference's L3/L4 classes (see rgbdslam_host.hpp).
 // No kernels here: all device work goes through the C ABI of include/rgbdslam.h.
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include "rgbdslam_host.hpp"
 
 #include <algorithm>
@@ -12,6 +13,15 @@
 #include <string.h>
 
 namespace slam {
+
+// roctx ranges round the five stages of the hot path (the reference times them with clock() behind TIMING,
+// GP-demo.cpp:153-277): visible in `rocprofv3 --marker-trace`, ~16 ns per range when no tool is attached.
+struct StageRange {
+    explicit StageRange(const char *name) { roctxRangePush(name); }
+    ~StageRange() { roctxRangePop(); }
+};
+
+
 
 void check(int rc, const char *what) {
     if (rc != 0) throw Error(what, rc);
@@ -520,6 +530,29 @@ void Graph::Clear() {
     _nodes.clear();
     _tables_built = false;
 }
+void Graph::Compact(const std::vector<int32_t> &Assoc) {
+    // a primitive's slabs are pool entries at its own index: the pool is reordered with the nodes (kept ones first, in order;
+    // the slabs of dropped primitives go back behind them and are wiped when AddPrimitive hands them out again)
+    std::vector<Primitive *> kept;
+    std::vector<DevBuf<uint16_t> *> b;
+    std::vector<DevBuf<uint8_t> *> r, k;
+    std::vector<DevBuf<uint64_t> *> c;
+    std::vector<size_t> rest;
+    for (size_t i = 0; i < _data_Bump_dev.size(); i++) {
+        const bool keep = i < _nodes.size() && i < Assoc.size() && Assoc[i] != 0;
+        if (keep) {
+            kept.push_back(_nodes[i]);
+            b.push_back(_data_Bump_dev[i]); r.push_back(_data_RGB_dev[i]); k.push_back(_data_Mask_dev[i]); c.push_back(_data_Claim_dev[i]);
+        } else {
+            if (i < _nodes.size()) delete _nodes[i];
+            rest.push_back(i);
+        }
+    }
+    for (size_t i : rest) { b.push_back(_data_Bump_dev[i]); r.push_back(_data_RGB_dev[i]); k.push_back(_data_Mask_dev[i]); c.push_back(_data_Claim_dev[i]); }
+    _nodes.swap(kept);
+    _data_Bump_dev.swap(b); _data_RGB_dev.swap(r); _data_Mask_dev.swap(k); _data_Claim_dev.swap(c);
+    _tables_built = false;
+}
 bool Graph::AddPrimitive(Primitive *Prim) {
     size_t idx = _nodes.size();
     if ((int)idx > _max_planes - 1) return false;                                  // Graph.h:103 (50 in the reference)
@@ -682,12 +715,14 @@ void RG::configure_streams() {
 }
 
 bool RG::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
+    StageRange r("stage 1: preprocessing (upload + OffLineFrame::LoadFrame)");
     configure_streams();
     _frame->LoadFrame(depth_host, bgr_host);                                        // RG.cpp:141
     _count++;                                                                       // RG.cpp:144
     return true;
 }
 bool RG::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
+    StageRange r("stage 1: preprocessing (OffLineFrame::LoadFrame)");
     configure_streams();
     _frame->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
     _count++;
@@ -994,6 +1029,50 @@ void RG::DetectPrimitives(float *pose) {
     hip_check(hipMemcpy(_predicted_frame->_Label_dev, Label_cpu.data(), P, hipMemcpyHostToDevice), "label upload");   // RG.cpp:590
 }
 
+// RG.cpp:934-1006: planes whose label is left on at most MIN_SIZE_PLAN pixels of the model frame are dropped, the others
+// renumbered in order; labels remapped (AffectPlan), equations compacted, centres = mean of the labelled points in the
+// global frame (VotePlan).  Two deliberate differences: the reference adds its votes onto UNINITIALISED device buffers
+// (RG.cpp:939-942: cudaMalloc without a memset) -- zeroed here -- and its unordered float atomics are a fixed summation
+// order in rgbdslam_vote_plan.  The reference calls it from RG::Finish right before a detection that overwrites everything
+// it produces (RG.cpp:266-267, labels cleared :313, _nbPlan = 0 :401), so Finish only runs it on request
+// (finish_reorganize); as a method of its own it compacts the plane set of a live tracker.
+int RG::ReorganizeEqua(float *pose) {
+    if (fused) Sync();
+    SyncAll();
+    if (_nbPlan <= 0) return 0;
+    const int n = _predicted_frame->_n, m = _predicted_frame->_m;
+    DevBuf<int32_t> Buff_dev; Buff_dev.alloc((size_t)_nbPlan);
+    DevBuf<float> Centers_dev; Centers_dev.alloc(3 * (size_t)_nbPlan);
+    DevBuf<float> count_dev; count_dev.alloc((size_t)_nbPlan);
+    check(rgbdslam_vote_plan(_ctx, _predicted_frame->_Label_dev, _predicted_frame->getVMap(), Centers_dev.p, count_dev.p, pose, _nbPlan,
+                             n, m), "VotePlan_cu");                                   // RG.cpp:946
+    std::vector<float> count_c((size_t)_nbPlan), centers_c(3 * (size_t)_nbPlan);
+    hip_check(hipMemcpy(count_c.data(), count_dev.p, 4 * (size_t)_nbPlan, hipMemcpyDeviceToHost), "count download");     // RG.cpp:951
+    hip_check(hipMemcpy(centers_c.data(), Centers_dev.p, 12 * (size_t)_nbPlan, hipMemcpyDeviceToHost), "centres download");
+    std::vector<int32_t> Assoc((size_t)_nbPlan);
+    int count = 0;
+    for (int i = 0; i < _nbPlan; i++) Assoc[i] = ((int)count_c[i] > min_size_plan) ? ++count : 0;                        // RG.cpp:955-962
+    hip_check(hipMemcpy(Buff_dev.p, Assoc.data(), 4 * (size_t)_nbPlan, hipMemcpyHostToDevice), "Assoc upload");
+    check(rgbdslam_affect_plan(_ctx, _predicted_frame->_Label_dev, Buff_dev.p, n, m), "AffectPlan_cu");                  // RG.cpp:965
+    std::vector<float> Eq(10 * (size_t)count), Ce(3 * (size_t)count);
+    for (int i = 0; i < _nbPlan; i++) {                                              // RG.cpp:972-990
+        if (Assoc[i] == 0) continue;
+        memcpy(&Eq[10 * (size_t)(Assoc[i] - 1)], &_Equations[10 * (size_t)i], 40);
+        for (int k = 0; k < 3; k++) Ce[3 * (size_t)(Assoc[i] - 1) + k] = centers_c[3 * (size_t)i + k] / count_c[i];
+    }
+    _Equations.swap(Eq); _Centers.swap(Ce);
+    _nbPlan = count;
+    // the reference leaves _Equations_dev NULL here (RG.cpp:997-998: the detection that follows allocates it again); a live
+    // tracker needs the compacted equations on the device, and its Graph must follow the renumbering
+    SyncAll();
+    _graph->Compact(Assoc);
+    if (count > 0) {
+        _Equations_dev.alloc(10 * (size_t)count, false);
+        hip_check(hipMemcpy(_Equations_dev.p, _Equations.data(), 40 * (size_t)count, hipMemcpyHostToDevice), "Equations");
+    }
+    return count;
+}
+
 int RG::DetectPlanes() {                                                              // RG.cpp:154-175
     if (fused) Sync();
     SyncAll();
@@ -1045,6 +1124,7 @@ void RG::Finish() {
     _posetPrev = _poset;
     if (can_dump) { StageTimer st("SaveModel"); SaveModel(save_dir.c_str(), _indx); finish_dumps++; }   // RG.cpp:209-232 (+ SaveThread, RG.cpp:16-59)
     _indx++;                                                                          // RG.cpp:234
+    if (finish_reorganize) { float pose[16]; pack_pose(_poseR, _poset, pose); ReorganizeEqua(pose); }   // RG.cpp:266 (its output is dead, see above)
     DetectPlanes();                                                                   // RG.cpp:253-268: tables freed, planes re-detected
     finish_detections++;
 }
@@ -1111,20 +1191,26 @@ int RG::StepAsync() {
     const bool ov = fused && overlap && (_overlap_mode & 2);
     if (ovl) _frame->wait_ready(main);
     if (first) _predicted_frame->ReseedFused(nullptr, 1, _frame);                   // GP-demo.cpp:164-167
+    StageRange r_frame("rgbdslam:display() pass");
     rgbdslam_icp_params prm = icp_params();
     const int slot = frames_done % HISTORY_CAP;
+    { StageRange r("stage 2+3: ICP + 27-term reduction (RG::AlignFrameGaussNewton)");
     check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _frame->getGx(), pitch, _frame->getGy(), pitch,
                                _predicted_frame->getVMap(), _predicted_frame->getNMap(), _predicted_frame->getRGB(), n, m, _pb_dev,
                                _history_dev.p, slot), "track_frame");               // GP-demo.cpp:189 + 201-245
+    }
     // the previous frame's Bump update (other stream) reads the model this frame is about to rewrite
     if (ov && _update_pending) hip_check(hipStreamWaitEvent(main, _ev_updated, 0), "wait for the previous update");
     // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
+    roctxRangePush("stage 5: prediction (Transform + raster + ReadFrame + ProjectMask/Label)");
     if (_deferred.valid) {                                                          // the previous frame's apply pass rides along
         _deferred.valid = false;
         _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame, &_deferred.t, _deferred.hist);
     } else {
         _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
     }
+    roctxRangePop();
+    roctxRangePush("stage 4: fusion (Segment + Merge + Graph::Update; next frame's stage 1 may ride)");
     UpdateTables upd;
     const bool claim_in_merge = !ov && _graph->begin_update(&upd);
     // when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides on a launch of this frame
@@ -1170,9 +1256,10 @@ int RG::StepAsync() {
             _update_pending = true;
         }
     }
+    roctxRangePop();
     _next_hint.valid = false;
     frames_done++;
-    Finish();                                                                       // GP-demo.cpp:274
+    { StageRange r("RG::Finish"); Finish(); }                                       // GP-demo.cpp:274
     return first ? 2 : 1;
 }
 
@@ -1664,6 +1751,15 @@ int slamhost_rg_set_finish(void *rg, int enabled, int first_after, int period, c
 int slamhost_rg_set_finish_reset_without_dump(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     ((RG *)rg)->finish_reset_without_dump = on != 0;
+    return 0;
+}
+// RG::ReorganizeEqua (RG.cpp:934-1006) on the current model frame; *nb = planes kept
+int slamhost_rg_reorganize_equa(void *rg, int *nb) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    RG *r = (RG *)rg;
+    int k = 0;
+    FACADE_TRY(float pose[16]; slam::pack_pose(r->_poseR, r->_poset, pose); k = r->ReorganizeEqua(pose));
+    if (nb) *nb = k;
     return 0;
 }
 int slamhost_rg_finish_skipped(void *rg) { return rg ? ((RG *)rg)->finish_skipped : -1; }

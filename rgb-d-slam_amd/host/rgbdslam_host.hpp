@@ -248,6 +248,8 @@ public:
     void ApplyTrackedAndPreprocess(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t, OffLineFrame *next,
                                    const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch);
     void Clear();
+    // keeps primitive i as number Assoc[i] - 1 (Assoc[i] = 0: dropped and freed); device tables rebuilt on the next update
+    void Compact(const std::vector<int32_t> &Assoc);
     std::vector<Primitive *> _nodes;
     int _SizeVBUFF[2];
     int plane_lo = 0, plane_hi = 0x7FFFFFFF;                       // plane-partitioned multi-GPU shard
@@ -294,6 +296,11 @@ public:
     // (RG.cpp:154-175): DetectPrimitives + CreatePrimitives on the current model frame; returns the plane count.
     void DetectPrimitives(float *pose);
     int DetectPlanes();
+    // RG.cpp:934-1006: drops the planes that hold at most MIN_SIZE_PLAN labelled pixels, renumbers the rest (labels, equations,
+    // centres = mean labelled point, the Graph's primitives); returns the planes kept.  RG::Finish calls it when
+    // finish_reorganize is set (in the reference everything it produces is overwritten by the detection that follows).
+    int ReorganizeEqua(float *pose);
+    bool finish_reorganize = false;
     // RG::Finish (RG.cpp:149-271), step 12 of display() (GP-demo.cpp:274): the first plane detection once _count > 30, then
     // every 100 frames the dump of the model (SaveModel into save_dir; synchronous -- the reference's Win32 SaveThread is
     // out of scope), the reset of the plane set and a new detection.  As in RG.cpp:177-187 the WHOLE periodic block is

@@ -176,3 +176,15 @@ def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():
     for o in (one, two):
         assert o["roofline"]["kernel"] == "k_vertex_from_bump_batch" and 0.0 < o["roofline"]["frac"] < 1.0
         assert o["unit"] == "steps/s" and o["value"] > 0
+
+
+def test_sequences_mode_two_ranks_on_one_card():
+    """BASELINE configs[4], the driver's own command (`bench.py --gpus N` through torch.distributed.run): one independent
+    sequence per rank, no data-path collective, value = all ranks' frames / max time.  Two ranks rehearsed on one card."""
+    one = _bench(["--steps", "40", "--warmup", "5", "--cpu-frames", "0", "--no-large-kernels", "--no-h2d"])
+    two = _bench(["--steps", "40", "--warmup", "5", "--cpu-frames", "0", "--no-large-kernels", "--no-h2d"], world=2)
+    for o, w in ((one, 1), (two, 2)):
+        assert o["n_gpus"] == w and o["scaling"] == "weak" and o["metric"].startswith("ICP+fusion frames/sec") and o["config"]["sequences"] == w
+        assert abs(o["value"] - 1e3 * w / o["ms_per_step"]) < 0.01 * o["value"]
+    assert two["config"]["icp"].startswith("12 k_icp_iter")      # ranks sharing a card cannot run the persistent kernel
+    assert two["value"] > 500 and one["value"] > 1000

@@ -491,3 +491,47 @@ def test_finish_schedule_first_detection_and_periodic_cycle(pkg, orc, synth, tmp
     assert model is not None and len(model["planes"]) == 3
     rg.close()
     ref.close()
+
+
+def test_reorganize_equa_drops_unseen_planes_and_renumbers(pkg, orc, synth):
+    """RG::ReorganizeEqua (D1/RG.cpp:934-1006) as a host method over VotePlan_cu / AffectPlan_cu: a plane nobody is labelled
+    with (injected FIRST, so that every other plane has to be renumbered) is dropped; labels, equations, centres and the Bump
+    images follow the renumbering -- after which the tracker is in exactly the state of a run that never had the extra plane."""
+    n, m, N_prim, frames = 120, 160, 256, 6
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(frames, n, m, calib, noise_sigma=0.0005)
+    eq, centers = synth.plane_equations()
+    bogus_eq = np.array([[0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 57.0]], np.float32)      # a plane 57 m away: no pixel lies on it
+    eq4 = np.concatenate([bogus_eq, eq]).astype(np.float32)
+    ce4 = np.concatenate([np.array([[0.0, 0.0, 57.0]], np.float32), centers]).astype(np.float32)
+    ref = orc.Slam(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg = pkg.RG(n, m, calib, N_prim=N_prim, M_prim=N_prim)
+    rg.set_finish(False, 30, 0, None, 300, 200)                  # MIN_SIZE_PLAN 300 at this image size
+    ref.set_finish(False)
+    for f, (d, c) in enumerate(seq):
+        assert ref.step(d, c) == (rg.load_frame(d, c) or rg.step())
+        if f == 1:
+            ref.set_planes(eq, centers)
+            rg.set_planes(eq4, ce4)
+        if f == 3:
+            lab_before = rg.buffer("Label")
+            assert set(np.unique(lab_before).tolist()) <= {0, 2, 3, 4} and (lab_before > 0).mean() > 0.5
+            v, pose = rg.buffer("VMap"), np.zeros(16, np.float32)
+            R, t = rg.pose()
+            pose[[0, 1, 2, 4, 5, 6, 8, 9, 10]] = np.array(R, np.float32); pose[12:15] = np.array(t, np.float32); pose[15] = 1.0
+            want_c, want_n = orc.vote_plan(lab_before, v, pose, 4)
+            eq_k, ce_k = rg.reorganize_equa()
+            assert eq_k.shape == (3, 10) and rg.finish_stats()["planes"] == 3
+            same(eq_k, eq, "equations compacted in order")
+            same(ce_k, (want_c.reshape(4, 3)[1:] / want_n[1:, None]).astype(np.float32), "centres = mean labelled point")
+            lab_after = rg.buffer("Label")
+            same(lab_after, np.where(lab_before > 0, lab_before - 1, 0).astype(np.uint8), "labels renumbered")
+    # two more frames were tracked and fused after the renumbering: same state as the run that only ever had three planes
+    for name in ("VMap", "NMap", "RGBD", "Mask", "Label"):
+        same(rg.buffer(name), ref.buffer(name), name)
+    for k in range(3):
+        assert int((ref.buffer("Maskb%d" % k) > 10).sum()) > 100
+        for slab in ("Maskb", "Bump", "RGBb"):
+            same(rg.buffer("%s%d" % (slab, k)), ref.buffer("%s%d" % (slab, k)), "%s%d" % (slab, k))
+    rg.close()
+    ref.close()
