@@ -507,6 +507,26 @@ int rgbdslam_detect_regions(rgbdslam_ctx *ctx, const float *NMap, const float *V
                             double canny_low, double canny_high, float thresh_discont, uint8_t thresh_edge,
                             int32_t *blob, int32_t *sizes, int32_t *work_labels, uint8_t *work_bytes, int n, int m);
 
+/* The per-blob median plane fit of RG::DetectPrimitives (RG.cpp:469-646: three sorted normal-component lists and one sorted
+ * distance list per blob, their middle elements, the in-plane basis, the blob centre) on the device: the middle element of a
+ * sorted list is found by a three-pass radix select over the image, so the floats are the ones `sort` + `[size / 2]` returns.
+ * blob / sizes: rgbdslam_find_blobs' / rgbdslam_detect_regions' outputs; VMap / NMap: the model frame; pose: HOST pointer,
+ * column-major 4x4.  workspace: rgbdslam_fit_planes_workspace_bytes(n, m) bytes of device memory, 256-byte aligned, owned by
+ * the caller; everything is enqueued on the context's stream.
+ * rgbdslam_fit_planes_read (BLOCKING): *nb_blobs = blobs of more than min_size pixels (RG.cpp:342-347); when it exceeds
+ * RGBDSLAM_FIT_MAX_BLOBS the records are incomplete and the caller fits on the host.  records_host: RGBDSLAM_FIT_MAX_BLOBS x
+ * RGBDSLAM_FIT_RECORD floats, in NO particular blob order: [0] root pixel (int bits) = FindBlobs' blob order, [1] size (int), [2]
+ * non-zero normals (int), [3] accepted (int: [2] >= min_normals, RG.cpp:500), [4..13] equation n(3) e1(3) e2(3) d, [17..19] centre.
+ * rgbdslam_fit_planes_label: Label[p] = label_of_slot_host[record index of p's blob], 0 elsewhere (RG.cpp:590). */
+#define RGBDSLAM_FIT_MAX_BLOBS 64
+#define RGBDSLAM_FIT_RECORD 20
+size_t rgbdslam_fit_planes_workspace_bytes(int n, int m);
+int rgbdslam_fit_planes(rgbdslam_ctx *ctx, const int32_t *blob, const int32_t *sizes, const float *VMap, const float *NMap,
+                        const float *pose16_host, int min_size, int min_normals, void *workspace, int n, int m);
+int rgbdslam_fit_planes_read(rgbdslam_ctx *ctx, const void *workspace, int *nb_blobs, float *records_host);
+int rgbdslam_fit_planes_label(rgbdslam_ctx *ctx, uint8_t *Label, const int32_t *blob, void *workspace,
+                              const uint8_t *label_of_slot_host, int n, int m);
+
 /* ---- prediction of the model directly from the Bump images (BASELINE configs[2] "fusion +
  * raycast partitioned by plane").  No call site in DemoStep1's loop (it predicts from the previous depth image); the meshes are
  * the reference's: VertexFromBump (Primitive.cuh:16, Primitive.cu:31-93) + QuadTrim (Primitive.cuh:18, Primitive.cu:95-152).

@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <future>
+#include <thread>
 #include <stdio.h>
 
 #include <math.h>
@@ -932,6 +934,44 @@ void RG::DetectPrimitives(float *pose) {
     hip_check(hipMemsetAsync(_predicted_frame->_Label_dev, 0, P, s), "memset label");                      // RG.cpp:313
     check(rgbdslam_detect_regions(_ctx, _predicted_frame->getNMap(), _predicted_frame->getVMap(), nullptr, 120.0, 30.0, 0.03f, 20,
                                   _blob_dev.p, _blob_sizes_dev.p, _detect_labels.p, _detect_bytes.p, n, m), "detect_regions");
+    _nbPlan = 0;                                                                      // RG.cpp:401
+    _Equations.clear(); _Centers.clear();
+    const int max_labels = 255;
+    // The median fit on the device (rgbdslam_fit_planes: radix select over the image instead of four downloads and three
+    // sorts per blob): only 80 bytes per blob come back.  Blob order, plane numbers and the 255 cap are applied here, in
+    // FindBlobs' order (ascending first pixel).  More blobs than the device path holds, or RGBDSLAM_HOST_FIT=1: the host fit below.
+    static const bool force_host_fit = getenv("RGBDSLAM_HOST_FIT") != nullptr;
+    if (!force_host_fit) {
+        StageTimer st_dev("  device median fit + labels");
+        const size_t need = rgbdslam_fit_planes_workspace_bytes(n, m);
+        if (_fit_ws.count < need) _fit_ws.alloc(need, false);
+        check(rgbdslam_fit_planes(_ctx, _blob_dev.p, _blob_sizes_dev.p, _predicted_frame->getVMap(), _predicted_frame->getNMap(), pose,
+                                  min_size_plan, min_normals_plan, _fit_ws.p, n, m), "fit_planes");
+        int nb = 0;
+        std::vector<float> rec((size_t)RGBDSLAM_FIT_MAX_BLOBS * RGBDSLAM_FIT_RECORD);
+        check(rgbdslam_fit_planes_read(_ctx, _fit_ws.p, &nb, rec.data()), "fit_planes_read");
+        if (nb <= RGBDSLAM_FIT_MAX_BLOBS) {
+            _Detect = nb > 0;                                                         // RG.cpp:385-390
+            if (!_Detect) return;
+            auto ival = [&](int slot, int k) { int v; memcpy(&v, &rec[(size_t)slot * RGBDSLAM_FIT_RECORD + k], 4); return v; };
+            std::vector<int> order((size_t)nb);
+            for (int k = 0; k < nb; k++) order[(size_t)k] = k;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return ival(a, 0) < ival(b, 0); });
+            uint8_t label_of_slot[RGBDSLAM_FIT_MAX_BLOBS] = {0};
+            for (int slot : order) {
+                if (_nbPlan >= max_labels) break;
+                if (!ival(slot, 3)) continue;                                         // RG.cpp:500-516: too few normals
+                const float *r = &rec[(size_t)slot * RGBDSLAM_FIT_RECORD];
+                label_of_slot[slot] = (uint8_t)(_nbPlan + 1);
+                for (int k = 0; k < 3; k++) _Centers.push_back(r[17 + k]);
+                _Equations.insert(_Equations.end(), r + 4, r + 14);
+                _nbPlan++;
+            }
+            check(rgbdslam_fit_planes_label(_ctx, _predicted_frame->_Label_dev, _blob_dev.p, _fit_ws.p, label_of_slot, n, m), "fit_planes_label");   // RG.cpp:590
+            hip_check(hipStreamSynchronize(s), "sync");                               // label_of_slot lives on this stack frame
+            return;
+        }
+    }
     StageTimer *st_dl = new StageTimer("  regions + 4 downloads");
     std::vector<int32_t> blob(P), sizes(P);
     std::vector<float> VMap_cpu(3 * P), NMap_cpu(3 * P);                              // RG.cpp:394-396
@@ -944,15 +984,12 @@ void RG::DetectPrimitives(float *pose) {
     delete st_dl;
     StageTimer st_fit("  host median fit + labels");
 
-    _nbPlan = 0;                                                                      // RG.cpp:401
-    _Equations.clear(); _Centers.clear();
     // blobs in FindBlobs' order = ascending first-pixel index; a blob's points = its pixels in raster order
     std::vector<size_t> roots;
     for (size_t p = 0; p < P; p++)
         if (sizes[p] > min_size_plan) roots.push_back(p);                             // RG.cpp:342-347
     _Detect = !roots.empty();                                                         // RG.cpp:385-390
     if (!_Detect) return;
-    const int max_labels = 255;
     // The fit of one blob is independent of the others' (the reference runs them one after the other on one core: ~8 ms for
     // three 100 000-pixel planes, the bulk of RG::Finish's periodic cycle): one task per blob, its three normal medians side
     // by side; what depends on the order of the blobs -- plane numbers, the 255 cap -- is applied afterwards, in order.
@@ -978,9 +1015,8 @@ void RG::DetectPrimitives(float *pose) {
         if (count < min_normals_plan) return;                                         // RG.cpp:500-516
         // RG.cpp:521-533 sorts the three lists and takes the middle elements: the same elements by selection
         auto mid = [](std::vector<float> &v) { std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return v[v.size() / 2]; };
-        std::future<float> fy = std::async(std::launch::async, mid, std::ref(Ny)), fz = std::async(std::launch::async, mid, std::ref(Nz));
         float nmle[3];
-        nmle[0] = mid(Nx); nmle[1] = fy.get(); nmle[2] = fz.get();
+        nmle[0] = mid(Nx); nmle[1] = mid(Ny); nmle[2] = mid(Nz);
         float norm_nmle = sqrtf((nmle[0] * nmle[0] + nmle[1] * nmle[1]) + nmle[2] * nmle[2]);
         nmle[0] = nmle[0] / norm_nmle; nmle[1] = nmle[1] / norm_nmle; nmle[2] = nmle[2] / norm_nmle;
         std::vector<float> Dists((size_t)curr_size);
@@ -1010,11 +1046,16 @@ void RG::DetectPrimitives(float *pose) {
         out.accepted = true;
     };
     {
-        std::vector<std::future<void>> tasks;
-        for (size_t r = 1; r < roots.size(); r++)
-            tasks.push_back(std::async(std::launch::async, fit_blob, roots[r], std::ref(fits[r])));
-        fit_blob(roots[0], fits[0]);
-        for (auto &t : tasks) t.get();
+        // a bounded pool: at most 8 workers pull blob indices from a counter -- a 1080p frame with a small
+        // min_size can hold hundreds of blobs, and a thread per blob (plus two per blob for the medians) could fail to start
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t workers = std::min<size_t>(roots.size(), std::min<size_t>(8, hw ? hw : 1));
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t r; (r = next.fetch_add(1)) < roots.size();) fit_blob(roots[r], fits[r]); };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < workers; w++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
     }
     for (size_t r = 0; r < roots.size(); r++) {
         if (_nbPlan >= max_labels) break;

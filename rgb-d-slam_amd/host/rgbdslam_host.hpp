@@ -389,7 +389,7 @@ private:
     float *_history_host = nullptr;
     int _history_synced = 0;
     DevBuf<int32_t> _blob_dev, _blob_sizes_dev, _detect_labels;
-    DevBuf<uint8_t> _detect_bytes;
+    DevBuf<uint8_t> _detect_bytes, _fit_ws;                        // _fit_ws: workspace of rgbdslam_fit_planes
     std::vector<int> _traj_count;                                  // dataset index of every processed frame
     std::vector<Mat3> _traj_R;                                     // unfused path: poses pushed by Step()
     std::vector<Vec3> _traj_t;
