@@ -248,6 +248,34 @@ class Context:
                                               C.c_float(thresh_discont), C.c_uint8(thresh_edge), _ptr(blob), _ptr(sizes),
                                               _ptr(work_labels), _ptr(work_bytes), n, m), "detect_regions")
 
+    def fit_planes(self, blob, sizes, vmap, nmap, pose, label, n, m, min_size=5000, min_normals=1000, max_labels=255):
+        """rgbdslam_fit_planes + _read + _label: the device median fit of RG::DetectPrimitives (D1/RG.cpp:469-646).
+        -> (blobs found, equations [k,10], centers [k,3]) in FindBlobs' order, or (blobs, None, None) when there are more blobs
+        than the device path holds; `label` (u8 image on the device) receives the plane numbers of the blobs' pixels."""
+        import numpy as np
+        import torch
+        self.lib.rgbdslam_fit_planes_workspace_bytes.restype = C.c_size_t
+        ws = torch.empty(self.lib.rgbdslam_fit_planes_workspace_bytes(n, m), dtype=torch.uint8, device="cuda")
+        _chk(self.lib.rgbdslam_fit_planes(self._h, _ptr(blob), _ptr(sizes), _ptr(vmap), _ptr(nmap), _host16(pose), int(min_size),
+                                          int(min_normals), _ptr(ws), n, m), "fit_planes")
+        nb = C.c_int()
+        rec = np.zeros((64, 20), np.float32)
+        _chk(self.lib.rgbdslam_fit_planes_read(self._h, _ptr(ws), C.byref(nb), C.c_void_p(rec.ctypes.data)), "fit_planes_read")
+        if nb.value > 64:
+            return nb.value, None, None
+        ri = rec.view(np.int32)
+        order = sorted(range(nb.value), key=lambda k: int(ri[k, 0]))
+        lab = (C.c_uint8 * 64)()
+        eq, ce = [], []
+        for k in order:
+            if len(eq) >= max_labels or not ri[k, 3]:
+                continue
+            lab[k] = len(eq) + 1
+            eq.append(rec[k, 4:14].copy()); ce.append(rec[k, 17:20].copy())
+        _chk(self.lib.rgbdslam_fit_planes_label(self._h, _ptr(label), _ptr(blob), _ptr(ws), lab, n, m), "fit_planes_label")
+        self.synchronize()
+        return nb.value, np.array(eq, np.float32).reshape(-1, 10), np.array(ce, np.float32).reshape(-1, 3)
+
     def transform_vertex_map(self, vmap, rgbd, n, m):
         _chk(self.lib.rgbdslam_transform_vertex_map(self._h, _ptr(vmap), _ptr(rgbd), n, m), "transform_vertex_map")
 

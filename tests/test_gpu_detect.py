@@ -184,3 +184,51 @@ def test_detect_regions_fused(ctx, orc, synth, shape, noise):
     same(host(blob), rb2)
     same(host(sizes), rs2)
     assert (rb2[: n // 2] == -1).all()
+
+
+@pytest.mark.parametrize("shape,grid,min_size,min_normals", [((480, 640), (3, 4), 5000, 1000), ((240, 320), (7, 8), 300, 200), ((96, 128), (1, 2), 100, 50)])
+def test_device_median_fit_equals_the_sorted_lists(ctx, orc, synth, shape, grid, min_size, min_normals):
+    """rgbdslam_fit_planes: the median plane fit of RG::DetectPrimitives (RG.cpp:469-646) by radix select over the image,
+    against the oracle's restatement that builds and sorts the lists: equations, centres (a serial float sum in raster order)
+    and labels bit-exact.  The frame is cut into a grid of blobs of different sizes (some below min_size), some pixels of a
+    blob carry zero normals (they stay in the lists as zeros), one blob has too few normals to be accepted, blobs interleave in
+    raster order, and a noisy pose rotates everything."""
+    n, m = shape
+    v, nm = scene(orc, synth, n, m, noise=0.003, seed=3)
+    rng = np.random.default_rng(n + m)
+    binary = np.zeros((n, m), np.uint8)
+    gr, gc = grid
+    hs, ws = n // gr, m // gc
+    for a in range(gr):
+        for b in range(gc):
+            shrink = int(rng.integers(2, min(hs, ws) // 3))        # blobs of different sizes, 4-connected and separate
+            binary[a * hs + 1:(a + 1) * hs - shrink, b * ws + 1:(b + 1) * ws - shrink] = 1
+    nm = nm.copy()
+    nm[rng.random((n, m)) < 0.05] = 0.0                             # holes in the normal map
+    nm[1:hs - 2, 1:ws - 2] = 0.0                                    # the first blob: (almost) no normals at all -> not accepted
+    blob, sizes = orc.find_blobs(binary)
+    R = synth.euler_xyz(0.11, -0.23, 0.07).astype(np.float32)
+    pose = np.eye(4, dtype=np.float32); pose[:3, :3] = R; pose[:3, 3] = [0.3, -0.2, 0.5]
+    pose16 = np.ascontiguousarray(pose.T.reshape(-1))
+    nb_want, eq_want, ce_want, lab_want = orc.fit_planes(blob, sizes, v, nm, pose16, np.zeros((n, m), np.uint8), min_size, min_normals, 255)
+    lab = torch.full((n, m), 99, dtype=torch.uint8, device="cuda")
+    found, eq, ce = ctx.fit_planes(dev(blob), dev(sizes), dev(v), dev(nm), pose16, lab, n, m, min_size, min_normals)
+    assert found == int((sizes > min_size).sum()) and found > nb_want >= 1, (found, nb_want)
+    same(eq, eq_want)
+    same(ce, ce_want)
+    same(host(lab), lab_want)
+
+
+def test_device_median_fit_reports_more_blobs_than_it_holds(ctx, orc, synth):
+    """More than RGBDSLAM_FIT_MAX_BLOBS blobs above min_size: the count comes back and the caller (RG::DetectPrimitives) fits on
+    the host instead."""
+    n, m = 240, 320
+    v, nm = scene(orc, synth, n, m)
+    binary = np.zeros((n, m), np.uint8)
+    for a in range(10):
+        for b in range(10):
+            binary[a * 24 + 1:a * 24 + 20, b * 32 + 1:b * 32 + 28] = 1
+    blob, sizes = orc.find_blobs(binary)
+    lab = torch.zeros(n, m, dtype=torch.uint8, device="cuda")
+    found, eq, ce = ctx.fit_planes(dev(blob), dev(sizes), dev(v), dev(nm), np.eye(4, dtype=np.float32).reshape(-1), lab, n, m, 100, 50)
+    assert found == 100 and eq is None
