@@ -106,7 +106,13 @@ void k_fit_hist(const int32_t *__restrict__ blob, const int32_t *__restrict__ ro
         const uint32_t key = fit_key(val[l]);
         bool act = in;
         if (pass > 0 && in) act = (key >> (shift + (pass == 2 ? 10 : 11))) == st[sl].prefix;
-        fit_wave_add(hist, act, (uint32_t)sl * FIT_BINS + ((key >> shift) & mask));
+        const uint32_t word = (uint32_t)sl * FIT_BINS + ((key >> shift) & mask);
+        // first pass: sign, exponent and two mantissa bits -- a planar blob's values share a few bins: one atomic per distinct bin
+        // of the wave.  Later passes see mantissa bits: still a handful of bins for the distances of a plane (aggregated:
+        // 37 us a pass against 97 us with one atomic per lane), all different for the noisy normals (one atomic per lane: 57 us
+        // against 69 us)
+        if (PHASE == 1 || pass == 0) fit_wave_add(hist, act, word);
+        else if (act) atomicAdd(hist + word, 1u);
     }
 }
 
@@ -162,52 +168,85 @@ __global__ void k_fit_normal(float *__restrict__ rec, const FitState *__restrict
 }
 
 // The blob centre: the reference adds the blob's points (global frame) one after the other, in raster order, in float
-// (RG.cpp:573-578) -- a serial sum by definition: 100 000 dependent additions for a wall of a 640 x 480 frame.  One
-// workgroup per blob, one wave per coordinate, walks the image in that order 64 pixels at a time; inside a group the sum
-// runs as a systolic chain over the lanes: lane L takes the running sum of lane L - 1 (DPP wave_shr:1; lane 0 takes the
-// carry of the groups before) and adds its own pixel's coordinate -- after 64 such steps lane 63 holds exactly what adding
-// the 64 pixels in order gives, at ONE vector instruction per pixel and no scalar traffic.  Pixels of the group that do
-// not belong to the blob add +0.0f (an exact identity), groups without a blob pixel are skipped, and the walk ends with the
-// blob's last pixel.  (A lane-by-lane readlane loop: ~60 cycles per pixel; this: 4-6.)
-__global__ __launch_bounds__(192)
+// (RG.cpp:573-578) -- a serial sum by definition: 100 000 dependent additions for a wall of a 640 x 480 frame, and the order
+// is part of the result.  One workgroup per blob walks the image in that order, in batches of 3 072 pixels, as a two-stage
+// pipeline: waves 1-3 STAGE the next batch (each owns 1 024 consecutive pixels: sixteen loads per lane in flight, the
+// blob's pixels transformed into the global frame and written DENSELY, in raster order, into the wave's own LDS region --
+// positions from ballots, no cross-wave step) while wave 0 CHAINS the batch before: lanes 0..2 own the x / y / z sums and
+// add their coordinate of one staged pixel after the other, four pixels per 16-byte LDS read.  One barrier per batch.
+// (Tried first: a systolic DPP chain over the lanes, one wave per coordinate -- exact too, but 8+ cycles per step and a
+// memory round trip per 64 pixels: 2.1 ms for three walls, then 0.83 ms batched; the host's nth_element fit took 2.7 ms.)
+#define FITC_PX 16                        // pixels per stager lane and batch
+#define FITC_SPAN (64 * FITC_PX)          // pixels per stager wave and batch
+#define FITC_STAGERS 3
+__global__ __launch_bounds__(256)
 void k_fit_center(const int32_t *__restrict__ blob, const float *__restrict__ VMap, PoseV Pz, float *__restrict__ rec,
                   const uint32_t *__restrict__ count, int P) {
-    const int s = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // w = coordinate of this wave
+    __shared__ __align__(16) float dense[2][FITC_STAGERS][3][FITC_SPAN + 4];
+    __shared__ int cnt[2][FITC_STAGERS];
+    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((uint32_t)s >= min(*count, (uint32_t)FIT_MAX_BLOBS)) return;
     const float *pose = Pz.v;
     const int root = __float_as_int(rec[FIT_REC * s]);
     const int size = __float_as_int(rec[FIT_REC * s + 1]);
-    const float q0 = pose[w], q1 = pose[4 + w], q2 = pose[8 + w], q3 = pose[12 + w];
-    auto fetch = [&](int base, bool &mine, float &x) {
-        const int p = base + lane;
-        mine = p < P && blob[p] == root;
-        x = 0.0f;
-        if (mine) {
-            const float V0 = VMap[3 * (size_t)p], V1 = VMap[3 * (size_t)p + 1], V2 = VMap[3 * (size_t)p + 2];
-            x = ((V0 * q0 + V1 * q1) + V2 * q2) + q3;
-        }
-    };
-    float carry = 0.0f;
-    int seen = 0;
-    int base = root & ~63;                           // the root is the blob's first pixel in raster order
-    bool mine, mine_n = false;
-    float x, x_n = 0.0f;
-    fetch(base, mine, x);
-    while (base < P && seen < size) {
-        if (base + 64 < P) fetch(base + 64, mine_n, x_n);                       // in flight while this group's chain runs
-        else { mine_n = false; x_n = 0.0f; }
-        const unsigned long long bits = __ballot(mine);
-        if (bits) {
-            seen += (int)__builtin_popcountll(bits);
-            float z = carry;
+    auto stage = [&](int buf, int b0) {              // stager waves only
+        const int v = wave - 1, span = b0 + v * FITC_SPAN;
+        int r[FITC_PX];
 #pragma unroll
-            for (int k = 0; k < 64; k++)
-                z = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(z), 0x138 /* wave_shr:1 */, 0xF, 0xF, false)) + x;
-            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 63));
+        for (int j = 0; j < FITC_PX; j++) {
+            const int p = span + 64 * j + lane;
+            r[j] = (p < P) ? blob[p] : -1;
         }
-        base += 64; mine = mine_n; x = x_n;
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < FITC_PX; j++) {
+            const int p = span + 64 * j + lane;
+            const bool mine = r[j] == root;          // root >= 0, so pixels beyond the image never match
+            const unsigned long long bits = __ballot(mine);
+            const size_t pc = mine ? (size_t)p : (size_t)root;
+            const float V0 = VMap[3 * pc], V1 = VMap[3 * pc + 1], V2 = VMap[3 * pc + 2];
+            if (mine) {
+                const int pos = base + (int)__builtin_popcountll(bits & ((1ull << lane) - 1ull));
+                dense[buf][v][0][pos] = ((V0 * pose[0] + V1 * pose[4]) + V2 * pose[8]) + pose[12];      // RG.cpp:566-571
+                dense[buf][v][1][pos] = ((V0 * pose[1] + V1 * pose[5]) + V2 * pose[9]) + pose[13];
+                dense[buf][v][2][pos] = ((V0 * pose[2] + V1 * pose[6]) + V2 * pose[10]) + pose[14];
+            }
+            base += (int)__builtin_popcountll(bits);
+        }
+        if (lane < 4) { dense[buf][v][0][base + lane] = 0.0f; dense[buf][v][1][base + lane] = 0.0f; dense[buf][v][2][base + lane] = 0.0f; }   // pad: + 0.0f is exact
+        if (lane == 0) cnt[buf][v] = base;
+    };
+    float c = 0.0f;                                  // wave 0, lane 0..2: the running sum of coordinate `lane`
+    int seen = 0, b0 = root;                         // the root is the blob's first pixel in raster order
+    if (wave > 0) stage(0, b0);
+    __syncthreads();
+    for (int it = 0;; it++) {
+        const int buf = it & 1;
+        if (wave > 0) {
+            stage(buf ^ 1, b0 + FITC_STAGERS * FITC_SPAN);
+        } else {
+            const int cl = lane < 3 ? lane : 0;
+            for (int v = 0; v < FITC_STAGERS; v++) {
+                const int nv = cnt[buf][v];
+                seen += nv;
+                const float4 *src = (const float4 *)dense[buf][v][cl];
+#pragma unroll 4
+                for (int k = 0; 4 * k < nv; k++) {
+                    const float4 q = src[k];
+                    c = c + q.x; c = c + q.y; c = c + q.z; c = c + q.w;
+                }
+            }
+        }
+        b0 += FITC_STAGERS * FITC_SPAN;
+        // (seen is wave 0's; every wave takes the decision from it through LDS)
+        __shared__ int done;
+        if (threadIdx.x == 0) done = (seen >= size || b0 >= P) ? 1 : 0;
+        __syncthreads();
+        const int d = done;
+        __syncthreads();                             // nobody overwrites `done` (next round) before everyone has read it
+        if (d) break;
     }
-    if (lane == 0) rec[FIT_REC * s + 17 + w] = carry / (float)size;             // RG.cpp:581-583
+    if (wave == 0 && lane < 3) rec[FIT_REC * s + 17 + lane] = c / (float)size;  // RG.cpp:581-583
 }
 
 // after the three passes of phase 1: the median distance and the in-plane basis (RG.cpp:598-646) -> equation (n, e1, e2, d)
@@ -279,7 +318,7 @@ extern "C" int rgbdslam_fit_planes(rgbdslam_ctx *ctx, const int32_t *blob, const
     for (int k = 0; k < 16; k++) Pz.v[k] = pose16_host[k];
     const dim3 gp((unsigned)((P + 255) / 256));
     KLAUNCH(ctx, k_fit_roots, gp, dim3(256), sizes, min_size, root_slot, rec, count, P);
-    KLAUNCH(ctx, k_fit_center, dim3(FIT_MAX_BLOBS), dim3(192), blob, VMap, Pz, rec, (const uint32_t *)count, P);
+    KLAUNCH(ctx, k_fit_center, dim3(FIT_MAX_BLOBS), dim3(256), blob, VMap, Pz, rec, (const uint32_t *)count, P);
     for (int pass = 0; pass < 3; pass++) {
         KLAUNCH(ctx, k_fit_hist<0>, gp, dim3(256), blob, (const int32_t *)root_slot, VMap, NMap, Pz, (const float *)rec, (const FitState *)st,
                 hist, nonzero, pass, P);
