@@ -263,6 +263,11 @@ def run_planes(args, env):
         shard = multigpu.PlaneShard(ctx, synth.tiled_planes(planes, N), N, rank, world, first_worker=first_worker)
         thin = args.pack == "thin"
         pipelined = bool(args.pipeline)
+        # tracker: the labels are maintained by the reference's own per-frame path, ProjectLabel + Segment_cu (Frame.cpp:385-405)
+        # with 16-bit label images, seeded ONCE by plane membership (the stand-in for detection);
+        # membership: every frame is labelled afresh by the stand-in (rounds 2-3)
+        labels_tracker = args.labels == "tracker"
+        labels_seeded = [False]
         # Pipelined step: rank 0 tracks frame f + 1 on a stream of its own (track_stream) while every rank --
         # rank 0 included -- fuses / decodes / predicts frame f on the work stream; two packs alternate, ordered by events.
         # The step time is then max(track, broadcast + work / N) instead of their sum.
@@ -290,9 +295,20 @@ def run_planes(args, env):
             rg = pkg.RG(n, m, calib, device=local, stream=track_stream.cuda_stream)
             rg.set_finish(False)                     # the model lives in the plane shards, not in the tracker's own Graph
             rg_ctx = rg.context()                    # label + export run on the tracker's stream
+            if labels_tracker:
+                rg.set_label16(True)                 # 256 planes: beyond the reference's unsigned char labels (Frame.h:197)
+            # The persistent ICP kernel needs every CU for itself (one workgroup per CU, all resident).  Beside the decode of
+            # planes on the SAME GPU (pipelined step, tracker owning planes) it does not get them: its workgroups trickle in as
+            # the decode's drain, the resident ones spin, and when the two start together the decode runs at half speed
+            # (kernel trace, profiles/r03_o_planes_trace.txt: 1 200 instead of 650 us on every third step).  There the loop runs
+            # as one launch per iteration, which interleaves; alone on its GPU (first_worker == 1) or in the serial step it
+            # is the one launch per frame.
+            loop_ok = bool(args.icp_loop) and (first_worker == 1 or not pipelined)
+            icp_form = "one launch per iteration"
             if world == 1 or "RGBDSLAM_BENCH_DEVICE" not in os.environ:
                 try:
-                    rg.set_icp_loop(bool(args.icp_loop))
+                    rg.set_icp_loop(loop_ok)
+                    icp_form = "persistent kernel" if loop_ok else icp_form
                 except RuntimeError:
                     pass
         order, k, d = [], 0, 1
@@ -325,12 +341,24 @@ def run_planes(args, env):
                     mark("k0", track_stream)
                 i = order[f]
                 rg.load_frame_device(depth_dev[i], bgr_dev[i])
+                if labels_tracker and labels_seeded[0] and f + 1 < len(order):   # the next frame's LoadFrame rides on this frame's merge launch
+                    rg.hint_next_device_frame(depth_dev[order[f + 1]], bgr_dev[order[f + 1]])
                 rg.step_async()
-                if thin:
+                if labels_tracker and not labels_seeded[0]:
+                    prm_ = synth.tiled_planes(planes, N)
+                    rg.set_plane_equations(np.concatenate([prm_[:, 0:3], prm_[:, 8:14], prm_[:, 3:4]], axis=1))
+                    rg.seed_labels_tiled(shard.t_param, planes, N, N)
+                    labels_seeded[0] = True
+                if thin and labels_tracker:              # RGBD.w, colour bytes, mask, labels and the history entry in ONE launch
+                    rg.export_frame_thin_labels(pk.buf, pk.off_w, pk.off_rgb8, pk.off_mask, pk.off_hist, pk.off_label)
+                elif thin:
                     rg.export_frame_thin(pk.buf, pk.off_w, pk.off_rgb8, pk.off_mask, pk.off_hist)
                 else:
                     rg.export_frame(pk.buf, pk.off_vmap, pk.off_rgbd, pk.off_mask, pk.off_hist)
-                shard.label(pk, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0], ctx=rg_ctx)
+                if labels_tracker and not thin:
+                    rg.export_labels(pk.buf, pk.off_label)
+                elif not labels_tracker:
+                    shard.label(pk, rg.buffer_ptr("VMap")[0], rg.buffer_ptr("NMap")[0], ctx=rg_ctx)
                 if mark:
                     mark("k1", track_stream)
                 if pipelined:
@@ -408,7 +436,7 @@ def run_planes(args, env):
             tracked = int((h[:, 12] == 1.0).sum())
             if tracked != args.steps:
                 raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
-            if args.icp_loop and rg.icp_loop_faults():
+            if loop_ok and rg.icp_loop_faults():
                 raise SystemExit("the persistent ICP kernel gave up waiting for its grid: result invalid")
         # ---- second pass (untimed): phases by events on rank 0's streams, decode kernel by the library's event hook ----
         phases = None
@@ -451,9 +479,13 @@ def run_planes(args, env):
                        "7 B (mask + Bump words) per cell of the 9 x 65 cells of every occupied tile + 8 B z-word per drawn pixel"),
                       ("k_planes_resolve", (8 + 3 * 10 + 12 + 16) * n * m, "z-word + three 10-byte cells read, VMap + RGBD written, per pixel")]
         # (every rank walks the same list: each pass runs steps, and a step holds collectives; the label kernel only runs on rank 0)
-        extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
+        if labels_tracker:
+            extra.append(("k_segment3_merge_claim", (72 + 2 + 9 + 49) * n * m,
+                          "tracker: Merge + three growth passes on u16 labels (no claim: the planes live in the shards) + the next frame's LoadFrame"))
+        else:
+            extra.append(("k_label_planes_l16", (12 + 12 + 2) * n * m + 56 * planes, "VMap + NMap read, u16 label written per pixel; 56 B per plane"))
         for kname, nbytes, what in extra:
-            kctx = rg_ctx._h if (kname == "k_label_planes_l16" and rank == 0) else ctx._h      # the label kernel runs on the tracker's context
+            kctx = rg_ctx._h if (kname in ("k_label_planes_l16", "k_segment3_merge_claim") and rank == 0) else ctx._h      # these run on the tracker's context
             if kname.startswith("k_planes_"):
                 kctx = ctx_pred._h                   # the prediction has a context (stream) of its own
             t_ms, cnt = _profile(lib, kctx, kname, lambda: [step() for _ in range(min(reps, 20))])
@@ -495,12 +527,12 @@ def run_planes(args, env):
                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[2]: 256 planes x 512x512 Bump cells tiled over the three planes of the synthetic room "
-                                      "corner; per step rank 0 tracks one 640x480 frame, labels it (u16) and broadcasts " + ("RGBD.w/colour bytes" if thin else "VMap/RGBD") + "/Mask/Label/pose "
+                                      "corner; per step rank 0 tracks one 640x480 frame, labels it (u16; " + ("ProjectLabel + Segment_cu in the tracker, seeded once by plane membership" if labels_tracker else "by plane membership, every frame") + ") and broadcasts " + ("RGBD.w/colour bytes" if thin else "VMap/RGBD") + "/Mask/Label/pose "
                                       "(%d bytes), every rank fuses it into and decodes the planes it owns%s" % (pack.nbytes,
                                       ", then draws them into a u64 z-buffer for the frame's view, all-reduce(MIN) of %d bytes, resolve" % (8 * n * m)
                                       if args.planes_predict else ""),
                           "planes_per_rank": shard.hi - shard.lo, "tracker_owns_planes": first_worker == 0,
-                          "broadcast_bytes": pack.nbytes, "pack": args.pack,
+                          "broadcast_bytes": pack.nbytes, "pack": args.pack, "labels": args.labels, "tracker_icp": icp_form,
                           "pipelined": pipelined, "backend": env["backend"],
                           "frames_resident_in_hbm": True},
                "roofline": {"bound": "hbm", "kernel": "k_vertex_from_bump_batch", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -638,6 +670,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="planes mode: 1 (default) = rank 0 tracks frame f+1 on its own stream beside the fusion / decode / prediction of "
                          "frame f; 0 = one stream, the phases one after the other")
+    ap.add_argument("--labels", default="tracker", choices=["tracker", "membership"],
+                    help="planes mode: tracker (default) = u16 labels maintained by ProjectLabel + Segment in the tracker, seeded once; "
+                         "membership = the plane-membership stand-in labels every frame")
     ap.add_argument("--tracker-works", default="auto", choices=["auto", "0", "1"],
                     help="planes mode: does rank 0 (the tracker) own planes too?  auto (default): yes below four ranks, no from four on")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "peer", "peer_loop"],

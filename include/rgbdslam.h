@@ -561,6 +561,21 @@ int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *history_ent
 int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float *VMap, const float *NMap,
                               const float *pose16_host, const float *history_entry_dev, float **ParamTab, int nb_planes,
                               int N_prim, int M_prim, float epsilon, float alpha, int n, int m);
+/* 16-bit labels through the TRACKER (round 3; no reference counterpart: PredictedFrame::_Label_dev is unsigned char, Frame.h:197,
+ * and so are the label arguments of ProjectMask_cu / Segment_cu / Update_cu).  rgbdslam_set_label_width(ctx, 2) makes every
+ * label image this context's entry points read or write a uint16_t image of n*m elements; the pointers keep their uint8_t type
+ * in the signatures (the u8 entry points stay the boundary, 1 = default).  It applies to: rgbdslam_model_predict[_apply]
+ * (Label_in / Label_out), rgbdslam_model_normal_segment, rgbdslam_model_segment_merge_claim[_preprocess],
+ * rgbdslam_model_merge_claim, rgbdslam_update / _update_tracked / _update_apply_tracked[_preprocess] / _update_from_history /
+ * _update_apply_from_history / _update_cu, rgbdslam_segment / _segment_cu, rgbdslam_seed_labels, rgbdslam_project_label,
+ * rgbdslam_fit_planes_label, rgbdslam_gpu_thresh / _detect_regions (Label argument), rgbdslam_vote_plan / _affect_plan;
+ * nbPlans may then reach 65535.  The *_l16 entry points above take u16 labels whatever the width.  Same kernels (templates on
+ * the label type), same arithmetic: a model of at most 255 planes gives the same labels at either width. */
+int rgbdslam_set_label_width(rgbdslam_ctx *ctx, int bytes_per_label);
+int rgbdslam_get_label_width(const rgbdslam_ctx *ctx);
+/* Kernel.cuh:24 ProjectMask_cu applied to the LABEL image (Frame.cpp:389, the gather of PredictedFrame::ProjectLabel):
+ * rgbdslam_project_mask with the context's label width (uses the context's pose, like rgbdslam_project_mask). */
+int rgbdslam_project_label(rgbdslam_ctx *ctx, const uint8_t *Label, uint8_t *Label_swap, const float *VMap, int n, int m);
 
 /* Thin frame pack for the plane-partitioned multi-GPU form (no reference counterpart: the reference is single-GPU; SURVEY.md
  * 8e row 1).  After PredictedFrame::Merge (Frame.cpp:300-333) the model VMap is VertexMapGL's function of RGBD.w
@@ -570,6 +585,11 @@ int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float 
  * (vertex and colour rebuilt with the reference's operations: the planes receive the same bits). */
 int rgbdslam_export_thin(rgbdslam_ctx *ctx, const float *RGBD, const uint8_t *Mask, float *W_out, uint8_t *RGB8_out,
                          uint8_t *Mask_out, int n, int m);
+/* rgbdslam_export_thin + the frame's u16 label image (as the tracker maintains it at label width 2) and its 64-byte history
+ * entry, in the same launch; either pair (Label16, Label16_out) / (history_entry_dev, history_entry_out) may be NULL */
+int rgbdslam_export_thin_l16(rgbdslam_ctx *ctx, const float *RGBD, const uint8_t *Mask, const uint16_t *Label16,
+                             const float *history_entry_dev, float *W_out, uint8_t *RGB8_out, uint8_t *Mask_out,
+                             uint16_t *Label16_out, float *history_entry_out, int n, int m);
 int rgbdslam_update_from_history_thin_l16(rgbdslam_ctx *ctx, const float *history_entry_dev, uint16_t **BumpTab, uint8_t **RGBTab,
                                           uint8_t **MaskTab, float **ParamTab, uint64_t **ClaimTab, uint32_t stamp, const float *W,
                                           const uint8_t *RGB8, const uint8_t *Mask, const uint16_t *Label16, int N_prim, int M_prim,

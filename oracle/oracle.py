@@ -285,13 +285,23 @@ def project_mask(pose, calib, mask, vmap):
 
 
 def segment(label, vmap, nmap, pose, equations, eps=0.1, alpha=0.9):
+    """3 x SegmentKernel; a uint16 label image goes through the 16-bit form (the build's extension, same statements)."""
     n, m, _ = vmap.shape
-    lab = np.ascontiguousarray(label, np.uint8).copy()
+    wide = np.asarray(label).dtype == np.uint16
+    lab = np.ascontiguousarray(label, np.uint16 if wide else np.uint8).copy()
     swap = np.empty_like(lab)
     eq = _f32(equations)
-    lib().orc_segment(_p(lab), _p(swap), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _p(eq),
-                      eq.size // 10, C.c_float(eps), C.c_float(alpha), n, m)
+    (lib().orc_segment_l16 if wide else lib().orc_segment)(_p(lab), _p(swap), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _p(eq),
+                                                           eq.size // 10, C.c_float(eps), C.c_float(alpha), n, m)
     return lab
+
+
+def project_label_l16(pose, calib, label16, vmap):
+    n, m, _ = vmap.shape
+    out = np.empty((n, m), np.uint16)
+    lib().orc_project_label_l16(_p(_f32(pose)), _p(_f32(calib)), _p(np.ascontiguousarray(label16, np.uint16)), _p(out),
+                                _p(_f32(vmap)), n, m)
+    return out
 
 
 def add_zbuff_off(depth, rgb, calib):
@@ -309,12 +319,12 @@ def init_mask(rgbd):
     return out
 
 
-def seed_labels(vmap, nmap, pose, equations, eps=0.1, alpha=0.8):
+def seed_labels(vmap, nmap, pose, equations, eps=0.1, alpha=0.8, wide=False):
     n, m, _ = vmap.shape
-    out = np.empty((n, m), np.uint8)
+    out = np.empty((n, m), np.uint16 if wide else np.uint8)
     eq = _f32(equations)
-    lib().orc_seed_labels(_p(out), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _p(eq), eq.size // 10,
-                          C.c_float(eps), C.c_float(alpha), n, m)
+    (lib().orc_seed_labels_l16 if wide else lib().orc_seed_labels)(_p(out), _p(_f32(vmap)), _p(_f32(nmap)), _p(_f32(pose)), _p(eq),
+                                                                   eq.size // 10, C.c_float(eps), C.c_float(alpha), n, m)
     return out
 
 
@@ -347,6 +357,11 @@ class Slam:
 
     def set_bilateral(self, on):
         self._lib.orc_slam_set_bilateral(self._h, int(on))
+
+    def set_label16(self, on):
+        """u16 label images (the build's extension for models of more than 255 planes); before any plane exists."""
+        self._lib.orc_slam_set_label16(self._h, int(on))
+        self._label16 = bool(on)
 
     def set_finish(self, enabled=True, first_after=30, period=100, min_size=-1, min_normals=-1):
         """RG::Finish schedule (D1/RG.cpp:149-271)."""
@@ -383,6 +398,8 @@ class Slam:
             return raw.view(np.float32).reshape(self.n, self.m, 3)
         if name == "RGBD":
             return raw.view(np.float32).reshape(self.n, self.m, 4)
+        if name == "Label" and raw.size == 2 * P:
+            return raw.view(np.uint16).reshape(self.n, self.m)
         if name in ("Mask", "Label"):
             return raw.reshape(self.n, self.m)
         if name.startswith("Bump"):

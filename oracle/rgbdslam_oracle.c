@@ -1227,31 +1227,44 @@ void orc_read_frame(float *VMap, float *RGBD, const float *tex, const float *cal
         }
 }
 
-void orc_project_mask(const float *pose, const float *calib, const uint8_t *mask,
-                      uint8_t *mask_swap, const float *V, int n, int m) {
+/* label images: unsigned char in the reference (Frame.h:197); `wide` = the build's 16-bit extension for models of more than
+ * 255 planes (same statements, wider element) */
+#define LGET(p, wide, i) ((wide) ? (int)((const uint16_t *)(p))[i] : (int)((const uint8_t *)(p))[i])
+#define LSET(p, wide, i, v) do { if (wide) ((uint16_t *)(p))[i] = (uint16_t)(v); else ((uint8_t *)(p))[i] = (uint8_t)(v); } while (0)
+
+static void project_mask_impl(const float *pose, const float *calib, const void *mask,
+                              void *mask_swap, int wide, const float *V, int n, int m) {
     #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < (size_t)n * m; idx++) {
         float a = V[3 * idx], b = V[3 * idx + 1], c = V[3 * idx + 2];
-        if (a == 0.0f && b == 0.0f && c == 0.0f) { mask_swap[idx] = 0; continue; }
+        if (a == 0.0f && b == 0.0f && c == 0.0f) { LSET(mask_swap, wide, idx, 0); continue; }
         float x = ((pose[0] * a + pose[4] * b) + pose[8] * c) + pose[12];
         float y = ((pose[1] * a + pose[5] * b) + pose[9] * c) + pose[13];
         float z = ((pose[2] * a + pose[6] * b) + pose[10] * c) + pose[14];
         int pu = f2i_rn((x / fabsf(z)) * calib[0] + calib[2]);                    /* Kernel.cu:653 */
         int pv = f2i_rn((y / fabsf(z)) * calib[1] + calib[3]);
-        if (pv > n - 1 || pu > m - 1 || pv < 0 || pu < 0) { mask_swap[idx] = 0; continue; }
-        mask_swap[idx] = mask[(size_t)pv * m + pu];
+        if (pv > n - 1 || pu > m - 1 || pv < 0 || pu < 0) { LSET(mask_swap, wide, idx, 0); continue; }
+        LSET(mask_swap, wide, idx, LGET(mask, wide, (size_t)pv * m + pu));
     }
 }
+void orc_project_mask(const float *pose, const float *calib, const uint8_t *mask,
+                      uint8_t *mask_swap, const float *V, int n, int m) {
+    project_mask_impl(pose, calib, mask, mask_swap, 0, V, n, m);
+}
+void orc_project_label_l16(const float *pose, const float *calib, const uint16_t *label,
+                           uint16_t *label_swap, const float *V, int n, int m) {
+    project_mask_impl(pose, calib, label, label_swap, 1, V, n, m);
+}
 
-static void segment_pass(const uint8_t *in, uint8_t *out, const float *VMap, const float *NMap,
+static void segment_pass(const void *in, void *out, int wide, const float *VMap, const float *NMap,
                          const float *pose, const float *Eq, float epsilon, float alpha, int n, int m) {
     float thresh_depth = 0.003f;                                                 /* RG.cu:269 */
     #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++)
         for (int j = 0; j < m; j++) {
             size_t idx = (size_t)i * m + j;
-            out[idx] = in[idx];
-            if (in[idx] > 0) continue;
+            LSET(out, wide, idx, LGET(in, wide, idx));
+            if (LGET(in, wide, idx) > 0) continue;
             int lb = i - 1 < 0 ? 0 : i - 1, ub = i + 2 > n ? n : i + 2;
             int lr = j - 1 < 0 ? 0 : j - 1, ur = j + 2 > m ? m : j + 2;
             float depth = VMap[3 * idx + 2];
@@ -1268,12 +1281,12 @@ static void segment_pass(const uint8_t *in, uint8_t *out, const float *VMap, con
             for (int ki = lb; ki < ub && !done; ki++)
                 for (int kj = lr; kj < ur; kj++) {
                     size_t nb = (size_t)ki * m + kj;
-                    if (in[nb] > 0 && fabsf(VMap[3 * nb + 2] - depth) < thresh_depth) {
-                        const float *E = Eq + 10 * ((int)in[nb] - 1);
+                    if (LGET(in, wide, nb) > 0 && fabsf(VMap[3 * nb + 2] - depth) < thresh_depth) {
+                        const float *E = Eq + 10 * (LGET(in, wide, nb) - 1);
                         float ed = (((p0) * E[0] + (p1) * E[1]) + (p2) * E[2]) - E[9];
                         float ea = (q0 * E[0] + q1 * E[1]) + q2 * E[2];
                         if (fabsf(ed) > epsilon || ea < alpha) continue;
-                        out[idx] = in[nb];
+                        LSET(out, wide, idx, LGET(in, wide, nb));
                         done = 1;
                         break;
                     }
@@ -1284,10 +1297,18 @@ static void segment_pass(const uint8_t *in, uint8_t *out, const float *VMap, con
 void orc_segment(uint8_t *Label, uint8_t *swap, const float *VMap, const float *NMap,
                  const float *pose, const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
     (void)nbPlans;
-    segment_pass(Label, swap, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
-    segment_pass(swap, Label, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
-    segment_pass(Label, swap, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    segment_pass(Label, swap, 0, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    segment_pass(swap, Label, 0, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    segment_pass(Label, swap, 0, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
     memcpy(Label, swap, (size_t)n * m);
+}
+void orc_segment_l16(uint16_t *Label, uint16_t *swap, const float *VMap, const float *NMap,
+                     const float *pose, const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
+    (void)nbPlans;
+    segment_pass(Label, swap, 1, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    segment_pass(swap, Label, 1, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    segment_pass(Label, swap, 1, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    memcpy(Label, swap, 2 * (size_t)n * m);
 }
 
 void orc_add_zbuff_off(const uint16_t *depth, size_t pitch, const float *rgb_in, float *RGBD,
@@ -1416,11 +1437,11 @@ void orc_init_mask(uint8_t *mask, const float *RGBD, int n, int m) {
     for (size_t idx = 0; idx < (size_t)n * m; idx++) mask[idx] = (RGBD[4 * idx + 3] == 0.0f) ? 10 : 11;
 }
 
-void orc_seed_labels(uint8_t *Label, const float *VMap, const float *NMap, const float *pose,
-                     const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
+static void seed_labels_impl(void *Label, int wide, const float *VMap, const float *NMap, const float *pose,
+                             const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
     #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < (size_t)n * m; idx++) {
-        Label[idx] = 0;
+        LSET(Label, wide, idx, 0);
         float n0 = NMap[3 * idx], n1 = NMap[3 * idx + 1], n2 = NMap[3 * idx + 2];
         if (n0 == 0.0f && n1 == 0.0f && n2 == 0.0f) continue;
         float l0 = VMap[3 * idx], l1 = VMap[3 * idx + 1], l2 = VMap[3 * idx + 2];
@@ -1430,15 +1451,23 @@ void orc_seed_labels(uint8_t *Label, const float *VMap, const float *NMap, const
         float q0 = (pose[0] * n0 + pose[4] * n1) + pose[8] * n2;
         float q1 = (pose[1] * n0 + pose[5] * n1) + pose[9] * n2;
         float q2 = (pose[2] * n0 + pose[6] * n1) + pose[10] * n2;
-        for (int k = 0; k < nbPlans && k < 255; k++) {
+        for (int k = 0; k < nbPlans && k < (wide ? 65535 : 255); k++) {
             const float *E = Eq + 10 * k;
             float ed = ((p0 * E[0] + p1 * E[1]) + p2 * E[2]) - E[9];
             float ea = (q0 * E[0] + q1 * E[1]) + q2 * E[2];
             if (fabsf(ed) > epsilon || ea < alpha) continue;
-            Label[idx] = (uint8_t)(k + 1);
+            LSET(Label, wide, idx, k + 1);
             break;
         }
     }
+}
+void orc_seed_labels(uint8_t *Label, const float *VMap, const float *NMap, const float *pose,
+                     const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
+    seed_labels_impl(Label, 0, VMap, NMap, pose, Eq, nbPlans, epsilon, alpha, n, m);
+}
+void orc_seed_labels_l16(uint16_t *Label, const float *VMap, const float *NMap, const float *pose,
+                         const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
+    seed_labels_impl(Label, 1, VMap, NMap, pose, Eq, nbPlans, epsilon, alpha, n, m);
 }
 
 /* ===================================================================================== */
@@ -1454,7 +1483,8 @@ struct orc_slam {
     uint16_t *depth;
     /* predicted frame (D1/Frame.h:188-282) */
     float *V, *N, *RGBD, *tex;
-    uint8_t *Mask, *MaskSwap, *Label, *LabelSwap;
+    uint8_t *Mask, *MaskSwap, *Label, *LabelSwap;   /* Label / LabelSwap: 2 bytes per pixel allocated; u16 images when label16 */
+    int label16;                    /* 16-bit label images (extension: models of more than 255 planes; Frame.h:197 keeps u8) */
     uint64_t *zbuf;
     /* planes (D1/Graph.h:54-116, D1/Primitive.h:180-190) */
     uint16_t **Bump; uint8_t **RGBb; uint8_t **Maskb; float **Param; uint64_t **Claim;
@@ -1482,7 +1512,7 @@ orc_slam *orc_slam_create(int n, int m, const float *calib, const orc_icp_params
     s->V = (float *)calloc(3 * P, 4); s->N = (float *)calloc(3 * P, 4); s->RGBD = (float *)calloc(4 * P, 4);
     s->tex = (float *)calloc(4 * P, 4);
     s->Mask = (uint8_t *)calloc(P, 1); s->MaskSwap = (uint8_t *)calloc(P, 1);
-    s->Label = (uint8_t *)calloc(P, 1); s->LabelSwap = (uint8_t *)calloc(P, 1);
+    s->Label = (uint8_t *)calloc(P, 2); s->LabelSwap = (uint8_t *)calloc(P, 2);
     s->zbuf = (uint64_t *)calloc(P, 8);
     s->Bump = (uint16_t **)calloc(max_planes, sizeof(void *)); s->RGBb = (uint8_t **)calloc(max_planes, sizeof(void *));
     s->Maskb = (uint8_t **)calloc(max_planes, sizeof(void *)); s->Param = (float **)calloc(max_planes, sizeof(void *));
@@ -1540,7 +1570,7 @@ void orc_slam_set_planes(orc_slam *s, const float *eq, const float *centers, int
     nb = install_planes(s, eq, centers, nb);
     float pose[16];
     pack_pose(s->poseR, s->poset, pose);
-    orc_seed_labels(s->Label, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, s->n, s->m);
+    seed_labels_impl(s->Label, s->label16, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, s->n, s->m);
 }
 
 /* RG::Finish's first branch (RG.cpp:154-175): DetectPrimitives (277-694) + CreatePrimitives (699-793) on the
@@ -1558,7 +1588,7 @@ int orc_slam_detect_planes(orc_slam *s, int min_size, int min_normals, float *eq
     }
     orc_sum(img, e[0], e[1], e[2], n, m);                                          /* RG.cpp:304 */
     orc_discont(img, s->V, n, m, 0.03f);                                           /* RG.cpp:307 */
-    memset(s->Label, 0, P);                                                        /* RG.cpp:313 */
+    memset(s->Label, 0, 2 * P);                                                    /* RG.cpp:313 */
     orc_thresh(img2, img, 20, s->Label, n, m);                                     /* RG.cpp:315 */
     orc_erode_ellipse5(er, img2, n, m);                                            /* RG.cpp:320-326 */
     int32_t *blob = (int32_t *)malloc(P * 4), *sizes = (int32_t *)malloc(P * 4);
@@ -1566,7 +1596,12 @@ int orc_slam_detect_planes(orc_slam *s, int min_size, int min_normals, float *eq
     float *eq = (float *)calloc((size_t)10 * s->max_planes, 4), *ce = (float *)calloc((size_t)3 * s->max_planes, 4);
     int nb = orc_fit_planes(blob, sizes, s->V, s->N, pose, s->Label, eq, ce, n, m, min_size, min_normals, s->max_planes);
     nb = install_planes(s, eq, ce, nb);
-    if (nb > 0) orc_segment(s->Label, s->LabelSwap, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, n, m);   /* RG.cpp:786 */
+    if (s->label16) {                                   /* the fit numbers its planes 1..nb <= 255: widen the blob labels */
+        uint16_t *w = (uint16_t *)s->Label;
+        for (size_t p = P; p-- > 0;) w[p] = s->Label[p];
+    }
+    if (nb > 0 && s->label16) orc_segment_l16((uint16_t *)s->Label, (uint16_t *)s->LabelSwap, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, n, m);
+    else if (nb > 0) orc_segment(s->Label, s->LabelSwap, s->V, s->N, pose, s->Eq, nb, 0.1f, 0.8f, n, m);   /* RG.cpp:786 */
     if (equations_out) memcpy(equations_out, eq, (size_t)40 * nb);
     if (centers_out) memcpy(centers_out, ce, (size_t)12 * nb);
     free(ch); free(img); free(img2); free(er); free(blob); free(sizes); free(eq); free(ce);
@@ -1623,9 +1658,11 @@ int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr) {
     pack_pose(s->poseR, s->poset, Pg);
     orc_project_mask(Pinv, s->calib, s->Mask, s->MaskSwap, s->V, n, m);
     { uint8_t *t = s->Mask; s->Mask = s->MaskSwap; s->MaskSwap = t; }
-    orc_project_mask(Pinv, s->calib, s->Label, s->LabelSwap, s->V, n, m);
+    project_mask_impl(Pinv, s->calib, s->Label, s->LabelSwap, s->label16, s->V, n, m);
     { uint8_t *t = s->Label; s->Label = s->LabelSwap; s->LabelSwap = t; }
-    if (s->nb_planes > 0)
+    if (s->nb_planes > 0 && s->label16)
+        orc_segment_l16((uint16_t *)s->Label, (uint16_t *)s->LabelSwap, s->V, s->N, Pg, s->Eq, s->nb_planes, 0.1f, 0.9f, n, m);
+    else if (s->nb_planes > 0)
         orc_segment(s->Label, s->LabelSwap, s->V, s->N, Pg, s->Eq, s->nb_planes, 0.1f, 0.9f, n, m);
     /* 9. */
     memcpy(s->poseRPrev, s->poseR, 36); memcpy(s->posetPrev, s->poset, 12);
@@ -1636,6 +1673,10 @@ int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr) {
     /* 11. Graph::Update (Graph.cpp:50-95) */
     if (s->nb_planes > 0) {
         s->stamp++;
+        if (s->label16)
+            orc_update_l16(s->Bump, s->RGBb, s->Maskb, s->Param, s->Claim, s->stamp, s->V, s->RGBD, s->Mask,
+                           (const uint16_t *)s->Label, Pg, s->N_prim, s->M_prim, n, m, 0, s->nb_planes);
+        else
         orc_update(s->Bump, s->RGBb, s->Maskb, s->Param, s->Claim, s->stamp, s->V, s->RGBD, s->Mask,
                    s->Label, Pg, s->N_prim, s->M_prim, n, m, 0, s->nb_planes);
     }
@@ -1658,6 +1699,11 @@ int orc_slam_step(orc_slam *s, const uint16_t *depth, const uint8_t *bgr) {
 }
 
 void orc_slam_set_bilateral(orc_slam *s, int on) { s->bilateral = on; }
+/* before any plane exists: the label images become u16 (cleared) */
+void orc_slam_set_label16(orc_slam *s, int on) {
+    s->label16 = on ? 1 : 0;
+    memset(s->Label, 0, 2 * (size_t)s->n * s->m); memset(s->LabelSwap, 0, 2 * (size_t)s->n * s->m);
+}
 void orc_slam_set_finish(orc_slam *s, int enabled, int first_after, int period, int min_size, int min_normals) {
     s->finish_enabled = enabled; s->finish_first_after = first_after; s->finish_period = period;
     if (min_size >= 0) s->finish_min_size = min_size;
@@ -1675,7 +1721,7 @@ const void *orc_slam_buffer(const orc_slam *s, const char *name, size_t *bytes) 
     else if (!strcmp(name, "NMap")) { p = s->N; b = 12 * P; }
     else if (!strcmp(name, "RGBD")) { p = s->RGBD; b = 16 * P; }
     else if (!strcmp(name, "Mask")) { p = s->Mask; b = P; }
-    else if (!strcmp(name, "Label")) { p = s->Label; b = P; }
+    else if (!strcmp(name, "Label")) { p = s->Label; b = s->label16 ? 2 * P : P; }
     else if (!strcmp(name, "frame.VMap")) { p = s->fV; b = 12 * P; }
     else if (!strcmp(name, "frame.NMap")) { p = s->fN; b = 12 * P; }
     else if (!strcmp(name, "frame.RGB")) { p = s->fRGB; b = 12 * P; }

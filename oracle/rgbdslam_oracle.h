@@ -210,6 +210,16 @@ void orc_update_l16(uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, flo
 void orc_label_planes_l16(uint16_t *Label16, const float *VMap, const float *NMap, const float *pose, float **ParamTab, int nb,
                           int N_prim, int M_prim, float epsilon, float alpha, int n, int m);
 
+/* 16-bit labels through the tracker (the build's extension; the reference's label image is unsigned char, Frame.h:197): the
+ * statements of orc_project_mask / orc_segment / orc_seed_labels on u16 images; checkers of rgbdslam_set_label_width(ctx, 2) */
+void orc_project_label_l16(const float *pose, const float *calib, const uint16_t *label, uint16_t *label_swap, const float *VMap,
+                           int n, int m);
+void orc_segment_l16(uint16_t *Label, uint16_t *Label_swap, const float *VMap, const float *NMap, const float *pose,
+                     const float *Equations, int nbPlans, float epsilon, float alpha, int n, int m);
+void orc_seed_labels_l16(uint16_t *Label, const float *VMap, const float *NMap, const float *pose, const float *Equations,
+                         int nbPlans, float epsilon, float alpha, int n, int m);
+void orc_slam_set_label16(orc_slam *s, int on);
+
 /* prediction from the planes: the Bump meshes (VertexFromBump Primitive.cu:31-93 + QuadTrim Primitive.cu:95-152) drawn with the
  * rasteriser rules of orc_raster; checkers of rgbdslam_planes_draw / rgbdslam_planes_resolve */
 void orc_planes_draw(uint64_t *zbuf, uint16_t **BumpTab, uint8_t **RGBTab, uint8_t **MaskTab, float **ParamTab, int plane_lo,

@@ -380,6 +380,18 @@ class Context:
     def project_mask(self, mask, mask_swap, vmap, n, m):
         _chk(self.lib.rgbdslam_project_mask(self._h, _ptr(mask), _ptr(mask_swap), _ptr(vmap), n, m), "project_mask")
 
+    def project_label(self, label, label_swap, vmap, n, m):
+        """ProjectMask_cu on the label image (Frame.cpp:389), read with the context's label width."""
+        _chk(self.lib.rgbdslam_project_label(self._h, _ptr(label), _ptr(label_swap), _ptr(vmap), n, m), "project_label")
+
+    def set_label_width(self, nbytes):
+        """1 (default): label images are u8 like the reference's (Frame.h:197); 2: every label image this context's entry
+        points read or write is a uint16 image (models of more than 255 planes)."""
+        _chk(self.lib.rgbdslam_set_label_width(self._h, int(nbytes)), "set_label_width")
+
+    def label_width(self):
+        return int(self.lib.rgbdslam_get_label_width(self._h))
+
     def segment(self, label, label_swap, vmap, nmap, pose, equations, nb, n, m, eps=0.1, alpha=0.9):
         _chk(self.lib.rgbdslam_segment(self._h, _ptr(label), _ptr(label_swap), _ptr(vmap), _ptr(nmap), _host16(pose),
                                        _ptr(equations), nb, C.c_float(eps), C.c_float(alpha), n, m), "segment")
@@ -468,6 +480,28 @@ class RG:
         out = np.empty((count, 16), np.float32)
         _hchk(self.lib.slamhost_rg_history(self._h, int(first), int(count), C.c_void_p(out.ctypes.data)), "history")
         return out
+
+    def set_label16(self, on):
+        """u16 label images through the whole tracker (ProjectLabel, Segment, Graph::Update) instead of the reference's
+        unsigned char (Frame.h:197): models of more than 255 planes.  Before any plane exists."""
+        _hchk(self.lib.slamhost_rg_set_label16(self._h, int(on)), "set_label16")
+        self._label16 = bool(on)
+
+    def set_plane_equations(self, equations):
+        """Tracker of a model whose Bump images live elsewhere (the tracking rank of the plane-partitioned form): the plane
+        equations [nb, 10] = (n, e1, e2, d) for ProjectLabel + Segment_cu (D1/Frame.cpp:385-405); nothing is fused here."""
+        import numpy as np
+        eq = np.ascontiguousarray(equations, np.float32)
+        _hchk(self.lib.slamhost_rg_set_plane_equations(self._h, C.c_void_p(eq.ctypes.data), int(eq.size // 10)), "set_plane_equations")
+
+    def seed_labels_tiled(self, param_tab, nb, N_prim, M_prim):
+        """Detection stand-in for a tiled model (needs set_label16): the current model frame's labels by plane membership incl.
+        the patch bounds (rgbdslam_label_planes_l16); param_tab = device table of nb 14-float parameter blocks."""
+        _hchk(self.lib.slamhost_rg_seed_labels_tiled(self._h, _ptr(param_tab), int(nb), int(N_prim), int(M_prim)), "seed_labels_tiled")
+
+    def export_labels(self, dst, off_label):
+        """Copies the label image of the frame just processed into dst + off_label (stream-ordered)."""
+        _hchk(self.lib.slamhost_rg_export_labels(self._h, _ptr(dst), C.c_size_t(off_label)), "export_labels")
 
     def set_icp_loop(self, on):
         """True: all Gauss-Newton iterations of a frame run in ONE persistent kernel (needs the GPU to itself and a single
@@ -622,6 +656,11 @@ class RG:
         _hchk(self.lib.slamhost_rg_export_frame(self._h, _ptr(dst), C.c_size_t(off_vmap), C.c_size_t(off_rgbd), C.c_size_t(off_mask),
                                                 C.c_size_t(off_hist)), "export_frame")
 
+    def export_frame_thin_labels(self, dst, off_w, off_rgb8, off_mask, off_hist, off_label):
+        """export_frame_thin + the u16 label image the tracker maintains (set_label16), all in one launch."""
+        _hchk(self.lib.slamhost_rg_export_frame_thin_labels(self._h, _ptr(dst), C.c_size_t(off_w), C.c_size_t(off_rgb8), C.c_size_t(off_mask),
+                                                            C.c_size_t(off_hist), C.c_size_t(off_label)), "export_frame_thin_labels")
+
     def export_frame_thin(self, dst, off_w, off_rgb8, off_mask, off_hist):
         """Thin pack: RGBD.w (f32), the colour bytes, Mask and the history entry of the merged model frame (stream-ordered)."""
         _hchk(self.lib.slamhost_rg_export_frame_thin(self._h, _ptr(dst), C.c_size_t(off_w), C.c_size_t(off_rgb8), C.c_size_t(off_mask),
@@ -649,6 +688,8 @@ class RG:
         self.synchronize()
         out = np.empty(nb, np.uint8)
         _hchk(self.lib.slamhost_copy_to_host(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nb)), "copy_to_host")
+        if name == "Label" and nb == 2 * self.n * self.m:
+            return out.view("uint16").reshape(self.n, self.m)
         if name in self.BUFFER_DTYPES:
             dt, ch = self.BUFFER_DTYPES[name]
             a = out.view(dt)

@@ -68,9 +68,14 @@ struct rgbdslam_ctx {
     size_t claim_cells;
     uint32_t claim_stamp;
     uint8_t *label_swap; size_t label_swap_px;
+    int label_width;               // rgbdslam_set_label_width: bytes per element of the label images (1 = u8 as in Frame.h:197, 2 = u16)
     unsigned int *compat_counter;
 };
 void compat_release(rgbdslam_ctx *ctx);
+// label images: u8 (the reference's, Frame.h:197), or u16 after rgbdslam_set_label_width(ctx, 2) -- the entry points keep
+// their uint8_t pointer types and read / write the images with the width the context says
+static inline bool labels16(const rgbdslam_ctx *ctx) { return ctx->label_width == 2; }
+static inline int max_label(const rgbdslam_ctx *ctx) { return labels16(ctx) ? 65535 : 255; }
 
 // Launch on the context's stream; when the kernel's name is the one being profiled, bracket the
 // launch with a HIP event pair recorded on that same stream.
@@ -85,6 +90,14 @@ int raster_noalloc_setup(int device, unsigned long long **out);
 #define KLAUNCH(ctx, kern, grid, block, ...)                                         \
     do {                                                                             \
         bool _prof = (ctx)->prof_name && prof_begin((ctx), #kern);                   \
+        hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);        \
+        if (_prof) prof_end(ctx);                                                    \
+    } while (0)
+
+// the same with the profiled name given explicitly (kern may be a parenthesised template instance)
+#define KLAUNCH_AS(ctx, name, kern, grid, block, ...)                                \
+    do {                                                                             \
+        bool _prof = (ctx)->prof_name && prof_begin((ctx), name);                    \
         hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);        \
         if (_prof) prof_end(ctx);                                                    \
     } while (0)

@@ -67,8 +67,9 @@ __global__ void k_map_data_2_vbo(const uint8_t *__restrict__ color, const uint16
 // a row's contributions left to right from 0, then the row sums top to bottom from 0.  One workgroup per label, one
 // thread per row (the call runs once per 100 frames), row sums through LDS.
 #define VOTE_MAX_ROWS 4096
+template <typename LT>
 __global__ __launch_bounds__(256)
-void k_vote_plan(const uint8_t *__restrict__ Label, const float *__restrict__ VMap, float *__restrict__ centers,
+void k_vote_plan(const LT *__restrict__ Label, const float *__restrict__ VMap, float *__restrict__ centers,
                  float *__restrict__ count, PoseV P, int n, int m) {
     __shared__ float4 rows[VOTE_MAX_ROWS];
     __shared__ unsigned char any_row[VOTE_MAX_ROWS];
@@ -76,7 +77,7 @@ void k_vote_plan(const uint8_t *__restrict__ Label, const float *__restrict__ VM
     for (int i = threadIdx.x; i < n; i += 256) {
         float4 r; r.x = r.y = r.z = r.w = 0.0f;
         bool any = false;
-        const uint8_t *lab = Label + (size_t)i * m;
+        const LT *lab = Label + (size_t)i * m;
         for (int j = 0; j < m; j++) {
             if (lab[j] != L + 1) continue;
             F3 p = xf_point(P.v, ld3(VMap, (size_t)i * m + j));
@@ -97,12 +98,13 @@ void k_vote_plan(const uint8_t *__restrict__ Label, const float *__restrict__ VM
 }
 
 // ---- D1/RG.cu:539-555 AffectPlanKernel -------------------------------------------------------------------------------------
-__global__ void k_affect_plan(uint8_t *__restrict__ Label, const int32_t *__restrict__ Buff, int n, int m) {
+template <typename LT>
+__global__ void k_affect_plan(LT *__restrict__ Label, const int32_t *__restrict__ Buff, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
-    uint8_t l = Label[idx];
-    if (l != 0) Label[idx] = (uint8_t)Buff[l - 1];
+    LT l = Label[idx];
+    if (l != 0) Label[idx] = (LT)Buff[l - 1];
 }
 
 // ---- D1/Primitive.cu:502-556 OverlapKernel: counter[1] = occupied cells, counter[0] = those that land on plane param_in ------
@@ -168,17 +170,21 @@ extern "C" int rgbdslam_map_data_2_vbo(rgbdslam_ctx *ctx, const uint8_t *colorFr
 extern "C" int rgbdslam_vote_plan(rgbdslam_ctx *ctx, const uint8_t *Label, const float *VMap, float *centers_dev, float *count_dev,
                                   const float *pose16_host, int nbPlans, int n, int m) {
     if (!ctx || !Label || !VMap || !centers_dev || !count_dev || !pose16_host || n <= 0 || m <= 0 || nbPlans < 0) return RGBDSLAM_E_ARG;
-    if (nbPlans > 255 || n > VOTE_MAX_ROWS) return RGBDSLAM_E_LIMIT;
+    if (nbPlans > max_label(ctx) || n > VOTE_MAX_ROWS) return RGBDSLAM_E_LIMIT;
     if (nbPlans == 0) return 0;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = pose16_host[k];
-    KLAUNCH(ctx, k_vote_plan, dim3(nbPlans), dim3(256), Label, VMap, centers_dev, count_dev, P, n, m);
+    if (labels16(ctx))
+        KLAUNCH_AS(ctx, "k_vote_plan", (k_vote_plan<uint16_t>), dim3(nbPlans), dim3(256), (const uint16_t *)Label, VMap, centers_dev, count_dev, P, n, m);
+    else
+        KLAUNCH_AS(ctx, "k_vote_plan", (k_vote_plan<uint8_t>), dim3(nbPlans), dim3(256), Label, VMap, centers_dev, count_dev, P, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 extern "C" int rgbdslam_affect_plan(rgbdslam_ctx *ctx, uint8_t *Label, const int32_t *Buff_dev, int n, int m) {
     if (!ctx || !Label || !Buff_dev || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
-    KLAUNCH(ctx, k_affect_plan, grid2d(n, m), block2d(), Label, Buff_dev, n, m);
+    if (labels16(ctx)) KLAUNCH_AS(ctx, "k_affect_plan", (k_affect_plan<uint16_t>), grid2d(n, m), block2d(), (uint16_t *)Label, Buff_dev, n, m);
+    else KLAUNCH_AS(ctx, "k_affect_plan", (k_affect_plan<uint8_t>), grid2d(n, m), block2d(), Label, Buff_dev, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -244,7 +250,7 @@ extern "C" int rgbdslam_segment_cu(rgbdslam_ctx *ctx, uint8_t *Label, const floa
                                    const float *Equations_dev, int nbPlans, float epsilon, float alpha, int n, int m) {
     if (!ctx || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t px = (size_t)n * m;
+    const size_t px = (size_t)n * m * (size_t)ctx->label_width;   // bytes of one label image
     if (ctx->label_swap_px < px) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->label_swap) { (void)hipFree(ctx->label_swap); ctx->label_swap = nullptr; ctx->label_swap_px = 0; }

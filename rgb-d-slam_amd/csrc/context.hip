@@ -26,6 +26,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     for (int k = 0; k < 8; k++) c->xchg_peer[k] = nullptr;
     c->xchg_world = 0; c->xchg_rank = 0; c->xchg_seq = 0; c->xchg_delay_ticks = 0; c->xchg_tab_dev = nullptr;
     c->bil_lut = nullptr; c->bil_sigma_color = -1.0;
+    c->label_width = 1;
     c->prof_name = nullptr; c->prof_ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_launches = 0; c->prof_in_group = false;
     // this device's copy of the static z-buffer of rgbdslam_predict_raster_noalloc (predict.hip), resolved here so that
     // the entry point itself never has to
@@ -55,6 +56,15 @@ extern "C" int rgbdslam_set_stream(rgbdslam_ctx *ctx, void *stream) {
     ctx->stream = (hipStream_t)stream;
     return 0;
 }
+
+// Element width of every label image this context's entry points read or write: 1 = u8 (the reference's, Frame.h:197),
+// 2 = u16 (models of more than 255 planes; the pointers keep their uint8_t type in the signatures).
+extern "C" int rgbdslam_set_label_width(rgbdslam_ctx *ctx, int bytes) {
+    if (!ctx || (bytes != 1 && bytes != 2)) return RGBDSLAM_E_ARG;
+    ctx->label_width = bytes;
+    return 0;
+}
+extern "C" int rgbdslam_get_label_width(const rgbdslam_ctx *ctx) { return ctx ? ctx->label_width : RGBDSLAM_E_ARG; }
 
 extern "C" int rgbdslam_get_stream(rgbdslam_ctx *ctx, void **stream) {
     if (!ctx || !stream) return RGBDSLAM_E_ARG;

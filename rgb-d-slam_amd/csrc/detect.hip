@@ -220,10 +220,12 @@ __global__ void k_discont(uint8_t *__restrict__ mat, size_t pitch, const float *
     if (depth_step(VMap, i, j, n, m, thresh)) mat[(size_t)i * pitch + j] = 255;
 }
 __global__ void k_thresh(uint8_t *__restrict__ out, size_t op, const uint8_t *__restrict__ in, size_t ip, uint8_t thresh,
-                         const uint8_t *__restrict__ Label, int n, int m) {
+                         const uint8_t *__restrict__ Label, int l16, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
-    out[(size_t)i * op + j] = (in[(size_t)i * ip + j] > thresh || Label[(size_t)i * m + j] > 0) ? 0 : 255;
+    const size_t p = (size_t)i * m + j;
+    const bool labelled = l16 ? ((const uint16_t *)Label)[p] > 0 : Label[p] > 0;   // rgbdslam_set_label_width
+    out[(size_t)i * op + j] = (in[(size_t)i * ip + j] > thresh || labelled) ? 0 : 255;
 }
 // cv::erode with getStructuringElement(MORPH_ELLIPSE, 5x5): rows 00100 / 11111 / 11111 / 11111 / 00100; pixels
 // outside the image do not constrain the minimum
@@ -247,7 +249,7 @@ __global__ void k_erode5(uint8_t *__restrict__ dst, size_t dp, const uint8_t *__
 // fused: hysteresis output of the three channels -> mean -> depth step -> threshold (RG.cpp:304-315); img2 only
 __global__ void k_edge_binary(const uint8_t *__restrict__ map, const int *__restrict__ label, const uint8_t *__restrict__ flag,
                               const float *__restrict__ VMap, const uint8_t *__restrict__ Label, uint8_t *__restrict__ img2,
-                              float thresh_discont, uint8_t thresh_edge, int n, int m) {
+                              float thresh_discont, uint8_t thresh_edge, int l16, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     const size_t P = (size_t)n * m, p = (size_t)i * m + j;
@@ -256,7 +258,8 @@ __global__ void k_edge_binary(const uint8_t *__restrict__ map, const int *__rest
     for (int c = 0; c < 3; c++) e[c] = (map[c * P + p] && flag[c * P + label[c * P + p]]) ? 255 : 0;
     uint8_t v = edge_mean(e[0], e[1], e[2]);
     if (depth_step(VMap, i, j, n, m, thresh_discont)) v = 255;
-    img2[p] = (v > thresh_edge || (Label && Label[p] > 0)) ? 0 : 255;
+    const bool labelled = Label && (l16 ? ((const uint16_t *)Label)[p] > 0 : Label[p] > 0);
+    img2[p] = (v > thresh_edge || labelled) ? 0 : 255;
 }
 
 // =================================================================================================
@@ -319,7 +322,7 @@ extern "C" int rgbdslam_gpu_discont(rgbdslam_ctx *ctx, uint8_t *mat, size_t pitc
 extern "C" int rgbdslam_gpu_thresh(rgbdslam_ctx *ctx, uint8_t *out, size_t out_pitch, const uint8_t *in, size_t in_pitch,
                                    uint8_t thresh, const uint8_t *Label, int n, int m) {
     if (!ctx || !out || !in || !Label || n <= 0 || m <= 0 || out_pitch < (size_t)m || in_pitch < (size_t)m) return RGBDSLAM_E_ARG;
-    KLAUNCH(ctx, k_thresh, grid2d(n, m), block2d(), out, out_pitch, in, in_pitch, thresh, Label, n, m);
+    KLAUNCH(ctx, k_thresh, grid2d(n, m), block2d(), out, out_pitch, in, in_pitch, thresh, Label, labels16(ctx) ? 1 : 0, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -355,7 +358,7 @@ extern "C" int rgbdslam_detect_regions(rgbdslam_ctx *ctx, const float *NMap, con
     run_cc(ctx, map, (size_t)m, work_labels, nullptr, n, m, 3, 8);
     KLAUNCH(ctx, k_hyst_flag, grid3(n, m, 3), block2d(), (const uint8_t *)map, (const int *)work_labels, flag, n, m);
     KLAUNCH(ctx, k_edge_binary, grid2d(n, m), block2d(), (const uint8_t *)map, (const int *)work_labels, (const uint8_t *)flag, VMap,
-            Label, img2, thresh_discont, thresh_edge, n, m);
+            Label, img2, thresh_discont, thresh_edge, labels16(ctx) ? 1 : 0, n, m);
     KLAUNCH(ctx, k_erode5, grid2d(n, m), block2d(), binary, (size_t)m, (const uint8_t *)img2, (size_t)m, n, m);
     run_cc(ctx, binary, (size_t)m, blob, sizes, n, m, 1, 4);
     HIP_TRY(hipGetLastError());

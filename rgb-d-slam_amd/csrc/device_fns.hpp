@@ -316,11 +316,13 @@ __device__ __forceinline__ long project_source(const float *P, const CalibV &c, 
 }
 
 // ---- D1/RG.cu:252-320 SegmentKernel: label adopted by an unlabeled pixel (0 = none) ------------------
-__device__ __forceinline__ uint8_t segment_pixel(const uint8_t *__restrict__ in, const float *__restrict__ VMap, F3 nl,
-                                                 const float *P, const float *__restrict__ Eq, float epsilon, float alpha,
-                                                 int i, int j, int n, int m) {
+// LT = the label image's element type: uint8_t (the reference's, Frame.h:197) or uint16_t (models beyond 255 planes)
+template <typename LT>
+__device__ __forceinline__ LT segment_pixel(const LT *__restrict__ in, const float *__restrict__ VMap, F3 nl,
+                                            const float *P, const float *__restrict__ Eq, float epsilon, float alpha,
+                                            int i, int j, int n, int m) {
     size_t idx = (size_t)i * m + j;
-    uint8_t res = 0;
+    LT res = 0;
     F3 q = xf_dir(P, nl);
     if (!is_zero3(q)) {
         F3 pl = ld3(VMap, idx);
@@ -330,19 +332,19 @@ __device__ __forceinline__ uint8_t segment_pixel(const uint8_t *__restrict__ in,
         // The reference scans the 3x3 neighbourhood row by row and stops at the first neighbour that qualifies
         // (RG.cu:285-311).  All nine labels and depths are fetched first (independent loads, one round trip); the
         // scan then runs on registers in the same order, so the same neighbour wins.
-        uint8_t lab[9];
+        LT lab[9];
         float dz[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             int ki = i - 1 + k / 3, kj = j - 1 + k % 3;
             bool ok = ki >= 0 && ki < n && kj >= 0 && kj < m;
             size_t nb = ok ? (size_t)ki * m + kj : idx;
-            lab[k] = ok ? in[nb] : (uint8_t)0;
+            lab[k] = ok ? in[nb] : (LT)0;
             dz[k] = VMap[3 * nb + 2];
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            uint8_t l = lab[k];
+            LT l = lab[k];
             if (res == 0 && l > 0 && __builtin_fabsf(dz[k] - depth) < thresh_depth) {
                 const float *E = Eq + 10 * ((int)l - 1);
                 float ed = ((p.x * E[0] + p.y * E[1]) + p.z * E[2]) - E[9];

@@ -156,12 +156,13 @@ void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__r
 // ---- resolve + PredictedFrame::ReadFrame + ProjectMask + the gather of ProjectLabel -------------------
 // (Frame.cpp:229-245,372-393).  Reads model set "in", writes model set "out" (ping-pong): the texel
 // never reaches memory.  Also resets the z-buffer word.
-template <bool PROJ>
+// LT = element type of the label images: uint8_t (the reference's, Frame.h:197) or uint16_t (rgbdslam_set_label_width 2)
+template <bool PROJ, typename LT>
 __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap_in,
                                   const float *__restrict__ RGBD_in, const uint8_t *__restrict__ Mask_in,
-                                  const uint8_t *__restrict__ Label_in, unsigned long long *__restrict__ zbuf,
+                                  const LT *__restrict__ Label_in, unsigned long long *__restrict__ zbuf,
                                   float *__restrict__ VMap_out, float *__restrict__ RGBD_out, uint8_t *__restrict__ Mask_out,
-                                  uint8_t *__restrict__ Label_out, CalibV c, ReseedArgs rs, const ProjVert *__restrict__ pv,
+                                  LT *__restrict__ Label_out, CalibV c, ReseedArgs rs, const ProjVert *__restrict__ pv,
                                   const float *__restrict__ zw, int n, int m) {
     const bool tracked = pb_tracked(pb);               // round trip shared with the z-buffer word (see k_predict_draw)
     int px = blockIdx.x * TILE_W + threadIdx.x, py = blockIdx.y * TILE_H + threadIdx.y;
@@ -230,16 +231,17 @@ __global__ void k_predict_resolve(const rgbdslam_pose_block *__restrict__ pb, co
     *(float4 *)(RGBD_out + 4 * p) = o;
     long src = project_source(pb->P_rel_inv, c, v, n, m);          // Kernel.cu:634-667, for Mask and Label
     Mask_out[p] = (src < 0) ? (uint8_t)0 : Mask_in[src];
-    Label_out[p] = (src < 0) ? (uint8_t)0 : Label_in[src];
+    Label_out[p] = (src < 0) ? (LT)0 : Label_in[src];
 }
 
 // ---- ComputeNormal of ReadFrame (Frame.cpp:242) + first SegmentKernel pass (RG.cu:252-320) ------------
 // Eq == nullptr (no planes yet): normals only, labels copied.  Tile functions, so that launches can carry two jobs.
-struct SegArgs {
+template <typename LT>
+struct SegArgsT {
     const rgbdslam_pose_block *pb;
     float *NMap;                 // written by the first pass, read by the others
     const float *VMap;
-    const uint8_t *in; uint8_t *out;
+    const LT *in; LT *out;
     const float *Eq; float epsilon, alpha;
     int n, m;
     int lazy_normals;            // 1: NMap is scratch of the growth passes only -- written (and computed) where a pixel has no label
@@ -249,12 +251,13 @@ struct SegArgs {
 // Frame.cpp:242, and Merge overwrites them, Frame.cpp:331), and a growth pass looks at the normal of UNLABELED pixels only --
 // about 1 % of the image in the steady state.  When NMap is the passes' private scratch (lazy_normals) the ~330 instructions
 // of the four-triangle normal are spent only there; the labels that come out are the same.
-__device__ __forceinline__ void normal_segment_tile(const SegArgs &a, const int bx, const int by) {
+template <typename LT>
+__device__ __forceinline__ void normal_segment_tile(const SegArgsT<LT> &a, const int bx, const int by) {
     const bool tracked = pb_tracked(a.pb);             // round trip shared with the pixel's own loads
     int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
     if (i >= a.n || j >= a.m) return;
     size_t idx = (size_t)i * a.m + j;
-    uint8_t mine = a.in[idx];
+    LT mine = a.in[idx];
     if (a.lazy_normals) {
         if (!tracked) return;
         if (mine == 0) {
@@ -272,7 +275,8 @@ __device__ __forceinline__ void normal_segment_tile(const SegArgs &a, const int 
     a.out[idx] = mine;
 }
 // one later pass; returns the pixel's label (0 outside the image / when not tracked: `done` tells)
-__device__ __forceinline__ uint8_t segment_pass_tile(const SegArgs &a, const int bx, const int by, bool &done, size_t &idx_out) {
+template <typename LT>
+__device__ __forceinline__ LT segment_pass_tile(const SegArgsT<LT> &a, const int bx, const int by, bool &done, size_t &idx_out) {
     const bool tracked = pb_tracked(a.pb);             // round trip shared with the pixel's own loads
     int j = bx * TILE_W + threadIdx.x, i = by * TILE_H + threadIdx.y;
     done = false; idx_out = 0;
@@ -281,14 +285,16 @@ __device__ __forceinline__ uint8_t segment_pass_tile(const SegArgs &a, const int
     int mine_w = a.in[idx];
     asm volatile("" : "+v"(mine_w));                   // the load stays above the flag test
     if (!tracked) return 0;
-    uint8_t mine = (uint8_t)mine_w;
+    LT mine = (LT)mine_w;
     if (mine == 0) mine = segment_pixel(a.in, a.VMap, ld3(a.NMap, idx), a.pb->P_glob, a.Eq, a.epsilon, a.alpha, i, j, a.n, a.m);
     a.out[idx] = mine;
     done = true; idx_out = idx;
     return mine;
 }
-__global__ void k_normal_segment(SegArgs a) { normal_segment_tile(a, blockIdx.x, blockIdx.y); }
-__global__ void k_segment_pass_pb(SegArgs a) {
+template <typename LT>
+__global__ void k_normal_segment(SegArgsT<LT> a) { normal_segment_tile(a, blockIdx.x, blockIdx.y); }
+template <typename LT>
+__global__ void k_segment_pass_pb(SegArgsT<LT> a) {
     bool done; size_t idx;
     (void)segment_pass_tile(a, blockIdx.x, blockIdx.y, done, idx);
 }
@@ -303,6 +309,7 @@ struct MergeClaimArgs {
     uint8_t *const *MaskTab;
     unsigned long long *const *ClaimTab;
     const uint8_t *Label;
+    const uint16_t *Label16;     // non-null: 16-bit labels, Label unused (k_model_merge with a claim)
     uint32_t stamp;
     int N_prim, M_prim, plane_lo, plane_hi;
 };
@@ -375,8 +382,9 @@ __device__ __forceinline__ void merge_claim(const MergeClaimArgs &ca, const floa
 #define SG_WP (SG_W + 2)
 #define SG_QMAX ((TILE_W + 4) * (TILE_H + 4))
 #define SG_QCHUNKS ((SG_QMAX + TILE_W * TILE_H - 1) / (TILE_W * TILE_H))
-struct SegTileLds {
-    uint8_t lab[SG_H][SG_WP];
+template <typename LT>
+struct SegTileLdsT {
+    LT lab[SG_H][SG_WP];
     unsigned int qn;
     unsigned short qpos[SG_QMAX];                    // r * SG_WP + c of the queued pixel's cell in lab
     float eq[10 * SG_EQ_LDS];                        // the first planes' equations (a pass reads up to nine of them per pixel)
@@ -389,17 +397,19 @@ struct SegQueued {
 };
 // Labels of the tile + 3 rings: requested before the workgroup's first barrier (seg3_request), staged and queued after it
 // (seg3_stage; S.qn was zeroed before that barrier).
-struct SegTileRegs { uint8_t l[3]; bool queue[3]; float eq0; };
-__device__ __forceinline__ SegTileRegs seg3_request(const SegArgs &a, const int i0, const int j0, const int tid, SegTileLds &S) {
+template <typename LT>
+struct SegTileRegsT { LT l[3]; bool queue[3]; float eq0; };
+template <typename LT>
+__device__ __forceinline__ SegTileRegsT<LT> seg3_request(const SegArgsT<LT> &a, const int i0, const int j0, const int tid, SegTileLdsT<LT> &S) {
     if (tid == 0) S.qn = 0u;
-    SegTileRegs R;
+    SegTileRegsT<LT> R;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int e = tid + k * TILE_W * TILE_H;
         const int r = e / SG_W, c = e % SG_W;
         const int ii = i0 - SG_RING + r, jj = j0 - SG_RING + c;
         const bool ok = e < SG_H * SG_W && ii >= 0 && ii < a.n && jj >= 0 && jj < a.m;
-        R.l[k] = ok ? a.in[(size_t)ii * a.m + jj] : (uint8_t)0;
+        R.l[k] = ok ? a.in[(size_t)ii * a.m + jj] : (LT)0;
         // tile + 2 rings; a pixel on the image border has a zero normal (ComputeNormal) and can never get a label
         R.queue[k] = ok && r >= 1 && r < SG_H - 1 && c >= 1 && c < SG_W - 1 && ii >= 1 && ii <= a.n - 2 && jj >= 1 && jj <= a.m - 2;
     }
@@ -407,7 +417,8 @@ __device__ __forceinline__ SegTileRegs seg3_request(const SegArgs &a, const int 
     return R;
 }
 // returns whether the tile + 3 rings hold any label at all
-__device__ __forceinline__ bool seg3_stage(const SegArgs &a, const SegTileRegs &R, const int tid, SegTileLds &S) {
+template <typename LT>
+__device__ __forceinline__ bool seg3_stage(const SegArgsT<LT> &a, const SegTileRegsT<LT> &R, const int tid, SegTileLdsT<LT> &S) {
     bool any = false;
     const int neq = 10 * min(a.nb_eq, SG_EQ_LDS);
     if (tid < neq) S.eq[tid] = R.eq0;
@@ -433,14 +444,15 @@ __device__ __forceinline__ bool seg3_stage(const SegArgs &a, const SegTileRegs &
     return __syncthreads_or(any ? 1 : 0) != 0;
 }
 // after seg3_stage.  Returns the label of the thread's own pixel after the third pass.
-__device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, const int j0, const int tid, SegTileLds &S,
-                                               const bool any_label) {
+template <typename LT>
+__device__ __forceinline__ LT seg3_passes(const SegArgsT<LT> &a, const int i0, const int j0, const int tid, SegTileLdsT<LT> &S,
+                                          const bool any_label) {
 #ifdef SEG3_NOQUEUE                                  // (timing experiments only: the passes never run)
     const int nq = 0;
 #else
     const int nq = any_label ? (int)S.qn : 0;        // uniform
 #endif
-    uint8_t *const L = &S.lab[0][0];
+    LT *const L = &S.lab[0][0];
     if (nq > 0) {
         const float *__restrict__ V = a.VMap;
         const float *P = a.pb->P_glob;
@@ -473,7 +485,7 @@ __device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, c
             }
         }
         for (int pass = 0; pass < 3; pass++) {
-            uint8_t got[SG_QCHUNKS];
+            LT got[SG_QCHUNKS];
 #pragma unroll
             for (int ch = 0; ch < SG_QCHUNKS; ch++) {
                 got[ch] = 0;
@@ -481,10 +493,10 @@ __device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, c
                 const unsigned int zmask = Q[ch].zmask;
                 if (zmask != 0u && L[pos] == 0) {
                     const F3 p = Q[ch].p, q = Q[ch].q;
-                    uint8_t res = 0;
+                    LT res = 0;
 #pragma unroll
                     for (int k = 0; k < 9; k++) {                            // row by row, the first neighbour that qualifies (RG.cu:285-311)
-                        const uint8_t l = L[pos + (k / 3 - 1) * SG_WP + (k % 3 - 1)];
+                        const LT l = L[pos + (k / 3 - 1) * SG_WP + (k % 3 - 1)];
                         if (res == 0 && l > 0 && ((zmask >> k) & 1u)) {
                             const float *E = (l <= SG_EQ_LDS ? (const float *)S.eq : a.Eq) + 10 * ((int)l - 1);
                             const float ed = ((p.x * E[0] + p.y * E[1]) + p.z * E[2]) - E[9];
@@ -503,7 +515,7 @@ __device__ __forceinline__ uint8_t seg3_passes(const SegArgs &a, const int i0, c
         }
     }
     const int ii = i0 + (int)threadIdx.y, jj = j0 + (int)threadIdx.x;
-    return (ii < a.n && jj < a.m) ? S.lab[threadIdx.y + SG_RING][threadIdx.x + SG_RING] : (uint8_t)0;
+    return (ii < a.n && jj < a.m) ? S.lab[threadIdx.y + SG_RING][threadIdx.x + SG_RING] : (LT)0;
 }
 
 struct MergeArgs {
@@ -576,7 +588,8 @@ __device__ __forceinline__ void model_merge_tile(const MergeArgs &a, const int b
     // it held every wave of the tile back; here only this wave waits for it.
     if (ca.ParamTab) {
         const size_t cidx = in ? (size_t)i * m + j : 0;
-        merge_claim(ca, pb->P_glob, p, in ? smask[threadIdx.y][threadIdx.x] : (uint8_t)0, cidx, in, in ? (int)ca.Label[cidx] : 0);
+        merge_claim(ca, pb->P_glob, p, in ? smask[threadIdx.y][threadIdx.x] : (uint8_t)0, cidx, in,
+                    in ? (ca.Label16 ? (int)ca.Label16[cidx] : (int)ca.Label[cidx]) : 0);
     }
 }
 __global__ __launch_bounds__(TILE_W * TILE_H)
@@ -587,8 +600,9 @@ void k_model_merge(MergeArgs a) { model_merge_tile(a, blockIdx.x, blockIdx.y); }
 // the merge's inputs (7 bytes per pixel: .w, depth, mask -- no halo), so that the two kinds of tile stay independent and
 // run side by side (one after the other inside one workgroup, their dependent memory round trips added up: 20.6 us
 // against 25.2 us for the three launches at 640 x 480).
-__device__ __forceinline__ void segment3_claim_tile(const SegArgs &sg, const MergeArgs &mg, const int bx, const int by) {
-    __shared__ SegTileLds S;
+template <typename LT>
+__device__ __forceinline__ void segment3_claim_tile(const SegArgsT<LT> &sg, const MergeArgs &mg, const int bx, const int by) {
+    __shared__ SegTileLdsT<LT> S;
     if (!pb_tracked(sg.pb)) return;
     const int n = sg.n, m = sg.m;
     const int j0 = bx * TILE_W, i0 = by * TILE_H;
@@ -596,15 +610,16 @@ __device__ __forceinline__ void segment3_claim_tile(const SegArgs &sg, const Mer
     const int j = j0 + threadIdx.x, i = i0 + threadIdx.y;
     const bool in = i < n && j < m;
     const size_t idx = in ? (size_t)i * m + j : 0;
-    const SegTileRegs SR = seg3_request(sg, i0, j0, tid, S);
+    const SegTileRegsT<LT> SR = seg3_request(sg, i0, j0, tid, S);
     float w_old = mg.RGBD_in[4 * idx + 3];
     uint16_t d = ((const uint16_t *)((const char *)mg.depth + (size_t)(in ? n - i - 1 : 0) * mg.dpitch))[in ? j : 0];
     int mk = mg.Mask_in[idx];
     asm volatile("" : "+v"(w_old), "+v"(mk));
     __syncthreads();
     const bool any_label = seg3_stage(sg, SR, tid, S);
-    const uint8_t mine = seg3_passes(sg, i0, j0, tid, S, any_label);
+    const LT mine = seg3_passes(sg, i0, j0, tid, S, any_label);
     if (in) sg.out[idx] = mine;
+    if (!mg.ca.ParamTab) return;                     // a tracker without Bump images of its own (equations only): no claim pass
     int newmask;
     const float w = merge_pixel(w_old, d, (uint8_t)mk, mg.c, newmask);
     const F3 v = vertex_from_w(w, i, j, mg.c);
@@ -615,8 +630,9 @@ __device__ __forceinline__ void segment3_claim_tile(const SegArgs &sg, const Mer
 // tile rows of the image; rows from there on (if the grid has them) preprocess the NEXT input frame (OffLineFrame::LoadFrame
 // of frame f+1 into buffers nothing in this launch reads): the job is independent of everything here and its ~11 us of
 // dependent steps fit under this launch's own.
+template <typename LT>
 __global__ __launch_bounds__(TILE_W * TILE_H)
-void k_segment3_merge_claim(SegArgs sg, MergeArgs mg, PreprocessArgs pp, int rows2) {
+void k_segment3_merge_claim(SegArgsT<LT> sg, MergeArgs mg, PreprocessArgs pp, int rows2) {
     if ((int)blockIdx.y >= rows2) {
         frame_preprocess_tile(pp, blockIdx.x, (int)blockIdx.y - rows2);
     } else if (blockIdx.y & 1) {
@@ -628,21 +644,23 @@ void k_segment3_merge_claim(SegArgs sg, MergeArgs mg, PreprocessArgs pp, int row
 }
 // PredictedFrame::Merge does not read labels and the label growth does not read anything Merge writes (given a normal
 // map of its own): the first growth pass and the merge share a launch, tile rows alternating between the two jobs.
+template <typename LT>
 __global__ __launch_bounds__(TILE_W * TILE_H)
-void k_normal_segment_merge(SegArgs sg, MergeArgs mg) {
+void k_normal_segment_merge(SegArgsT<LT> sg, MergeArgs mg) {
     if (blockIdx.y & 1) model_merge_tile(mg, blockIdx.x, (int)(blockIdx.y >> 1));
     else normal_segment_tile(sg, blockIdx.x, (int)(blockIdx.y >> 1));
 }
 // last growth pass + the claim pass of Graph::Update for the same pixel (its merged vertex and mask were written by
 // the launch above)
+template <typename LT>
 __global__ __launch_bounds__(TILE_W * TILE_H)
-void k_segment_pass_claim(SegArgs sg, MergeClaimArgs ca, const float *__restrict__ VMap_merged, const uint8_t *__restrict__ Mask_merged) {
+void k_segment_pass_claim(SegArgsT<LT> sg, MergeClaimArgs ca, const float *__restrict__ VMap_merged, const uint8_t *__restrict__ Mask_merged) {
     bool done; size_t idx;
-    const uint8_t mine = segment_pass_tile(sg, blockIdx.x, blockIdx.y, done, idx);
+    const LT mine = segment_pass_tile(sg, blockIdx.x, blockIdx.y, done, idx);
     F3 v; v.x = v.y = v.z = 0.0f;
     uint8_t mc = 0;
     if (done) { v = ld3(VMap_merged, idx); mc = Mask_merged[idx]; }
-    if (!pb_tracked(sg.pb)) return;                  // wave-uniform
+    if (!pb_tracked(sg.pb) || !ca.ParamTab) return;  // wave-uniform
     merge_claim(ca, sg.pb->P_glob, v, mc, idx, done, (int)mine);
 }
 
@@ -675,9 +693,12 @@ extern "C" int rgbdslam_model_reseed(rgbdslam_ctx *ctx, const rgbdslam_pose_bloc
     return 0;
 }
 
+// The label images of every entry point below are u8, or u16 after rgbdslam_set_label_width(ctx, 2) (the pointers keep
+// their u8 type in the signatures); LT is the element type the launch reads them with.
+template <typename LT>
 static int model_predict_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *VMap_in,
-                              const float *RGBD_in, const uint8_t *Mask_in, const uint8_t *Label_in, uint64_t *zbuf,
-                              float *VMap_out, float *RGBD_out, uint8_t *Mask_out, uint8_t *Label_out, float thresh,
+                              const float *RGBD_in, const uint8_t *Mask_in, const LT *Label_in, uint64_t *zbuf,
+                              float *VMap_out, float *RGBD_out, uint8_t *Mask_out, LT *Label_out, float thresh,
                               float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
                               const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
                               void *vertex_scratch, const UpdateArgs *apply) {
@@ -702,13 +723,13 @@ static int model_predict_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose
     KLAUNCH(ctx, k_predict_draw, gd, block2d(), pose_block_dev, VMap_in, (unsigned long long *)zbuf, thresh,
             ctx->calib, znear, zfar, upd, rows_draw, pv, zw, n, m);
     if (pv)
-        KLAUNCH(ctx, k_predict_resolve<true>, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
-                (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs, (const ProjVert *)pv,
-                (const float *)zw, n, m);
+        KLAUNCH_AS(ctx, "k_predict_resolve<true>", (k_predict_resolve<true, LT>), grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in,
+                   Mask_in, Label_in, (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs,
+                   (const ProjVert *)pv, (const float *)zw, n, m);
     else
-        KLAUNCH(ctx, k_predict_resolve<false>, grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in,
-                (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs, (const ProjVert *)nullptr,
-                (const float *)nullptr, n, m);
+        KLAUNCH_AS(ctx, "k_predict_resolve<false>", (k_predict_resolve<false, LT>), grid2d(n, m), block2d(), pose_block_dev, VMap_in, RGBD_in,
+                   Mask_in, Label_in, (unsigned long long *)zbuf, VMap_out, RGBD_out, Mask_out, Label_out, ctx->calib, rs,
+                   (const ProjVert *)nullptr, (const float *)nullptr, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -718,6 +739,10 @@ extern "C" int rgbdslam_model_predict(rgbdslam_ctx *ctx, const rgbdslam_pose_blo
                                       float znear, float zfar, int n, int m, const float *frame_VMap, const float *frame_NMap,
                                       const float *frame_RGB, const uint16_t *depth, size_t depth_pitch, float *NMap_reseed,
                                       void *vertex_scratch) {
+    if (ctx && labels16(ctx))
+        return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, (const uint16_t *)Label_in, zbuf, VMap_out, RGBD_out,
+                                  Mask_out, (uint16_t *)Label_out, thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth,
+                                  depth_pitch, NMap_reseed, vertex_scratch, nullptr);
     return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in, zbuf, VMap_out, RGBD_out, Mask_out, Label_out,
                               thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed,
                               vertex_scratch, nullptr);
@@ -737,30 +762,45 @@ extern "C" int rgbdslam_model_predict_apply(rgbdslam_ctx *ctx, const rgbdslam_po
     if ((size_t)(n > 0 ? n : 0) * (size_t)(m > 0 ? m : 0) > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, prev_stamp, VMap_in, RGBD_in, Mask_in, Label_in,
-                    nullptr, P, nullptr, prev_history_entry_dev, N_prim, M_prim, n, m, plane_lo, plane_hi};
+    const bool l16 = ctx && labels16(ctx);
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, prev_stamp, VMap_in, RGBD_in, Mask_in,
+                    l16 ? nullptr : Label_in, l16 ? (const uint16_t *)Label_in : nullptr, P, nullptr, prev_history_entry_dev, N_prim, M_prim,
+                    n, m, plane_lo, plane_hi};
+    if (l16)
+        return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, (const uint16_t *)Label_in, zbuf, VMap_out, RGBD_out,
+                                  Mask_out, (uint16_t *)Label_out, thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth,
+                                  depth_pitch, NMap_reseed, vertex_scratch, &a);
     return model_predict_impl(ctx, pose_block_dev, VMap_in, RGBD_in, Mask_in, Label_in, zbuf, VMap_out, RGBD_out, Mask_out, Label_out,
                               thresh, znear, zfar, n, m, frame_VMap, frame_NMap, frame_RGB, depth, depth_pitch, NMap_reseed,
                               vertex_scratch, &a);
 }
 
+template <typename LT>
+static int model_normal_segment_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap, const float *VMap,
+                                     LT *Label, LT *Label_swap, const float *Equations_dev, int nbPlans, float epsilon, float alpha,
+                                     int n, int m) {
+    const float *Eq = nbPlans > 0 ? Equations_dev : nullptr;
+    SegArgsT<LT> p1 = {pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m, 0};
+    KLAUNCH_AS(ctx, "k_normal_segment", (k_normal_segment<LT>), grid2d(n, m), block2d(), p1);
+    if (Eq) {                                                    // passes 2 and 3 (D1/RG.cu:910-911)
+        SegArgsT<LT> p2 = p1, p3 = p1;
+        p2.in = Label_swap; p2.out = Label;
+        KLAUNCH_AS(ctx, "k_segment_pass_pb", (k_segment_pass_pb<LT>), grid2d(n, m), block2d(), p2);
+        KLAUNCH_AS(ctx, "k_segment_pass_pb", (k_segment_pass_pb<LT>), grid2d(n, m), block2d(), p3);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 extern "C" int rgbdslam_model_normal_segment(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap,
                                              const float *VMap, uint8_t *Label, uint8_t *Label_swap, const float *Equations_dev,
                                              int nbPlans, float epsilon, float alpha, int n, int m) {
     if (!ctx || !pose_block_dev || !NMap || !VMap || !Label || !Label_swap || Label == Label_swap || n <= 0 || m <= 0)
         return RGBDSLAM_E_ARG;
-    if (nbPlans < 0 || nbPlans > 255 || (nbPlans > 0 && !Equations_dev)) return RGBDSLAM_E_LIMIT;
-    const float *Eq = nbPlans > 0 ? Equations_dev : nullptr;
-    SegArgs p1 = {pose_block_dev, NMap, VMap, Label, Label_swap, Eq, epsilon, alpha, n, m, 0};
-    KLAUNCH(ctx, k_normal_segment, grid2d(n, m), block2d(), p1);
-    if (Eq) {                                                    // passes 2 and 3 (D1/RG.cu:910-911)
-        SegArgs p2 = p1, p3 = p1;
-        p2.in = Label_swap; p2.out = Label;
-        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p2);
-        KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p3);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    if (nbPlans < 0 || nbPlans > max_label(ctx) || (nbPlans > 0 && !Equations_dev)) return RGBDSLAM_E_LIMIT;
+    if (labels16(ctx))
+        return model_normal_segment_impl(ctx, pose_block_dev, NMap, VMap, (uint16_t *)Label, (uint16_t *)Label_swap, Equations_dev, nbPlans,
+                                         epsilon, alpha, n, m);
+    return model_normal_segment_impl(ctx, pose_block_dev, NMap, VMap, Label, Label_swap, Equations_dev, nbPlans, epsilon, alpha, n, m);
 }
 
 extern "C" int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, const float *RGBD_in,
@@ -770,7 +810,7 @@ extern "C" int rgbdslam_model_merge(rgbdslam_ctx *ctx, const rgbdslam_pose_block
         return RGBDSLAM_E_ARG;
     if (RGBD_in == RGBD_out || Mask_in == Mask_out || n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
+    MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
     MergeArgs a = {pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, ctx->calib, none, n, m};
     KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
@@ -788,7 +828,9 @@ extern "C" int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose
     if (RGBD_in == RGBD_out || Mask_in == Mask_out || n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;                   // 23-bit pixel index in the claim key
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, Label, stamp, N_prim, M_prim, plane_lo, plane_hi};
+    const bool l16 = labels16(ctx);
+    MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, l16 ? nullptr : Label, l16 ? (const uint16_t *)Label : nullptr,
+                         stamp, N_prim, M_prim, plane_lo, plane_hi};
     MergeArgs a = {pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, ctx->calib, ca, n, m};
     KLAUNCH(ctx, k_model_merge, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
@@ -799,8 +841,9 @@ extern "C" int rgbdslam_model_merge_claim(rgbdslam_ctx *ctx, const rgbdslam_pose
 // RGBDSLAM_SEG3=0, as the three launches this replaced: [first growth pass + merge] -> [second pass] -> [third pass +
 // claim], where NMap_seg = the normal map of the predicted frame that the growth passes use (not the merge's NMap_out).
 // Needs planes (nbPlans > 0).  next != nullptr: the next input frame's preprocessing rides along.
+template <typename LT>
 static int segment_merge_claim_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pose_block_dev, float *NMap_seg,
-                                    const float *VMap_pred, uint8_t *Label, uint8_t *Label_swap,
+                                    const float *VMap_pred, LT *Label, LT *Label_swap,
                                     const float *Equations_dev, int nbPlans, float epsilon, float alpha,
                                     const float *RGBD_in, const uint8_t *Mask_in, const uint16_t *depth,
                                     size_t depth_pitch, const float *RGB, float *RGBD_out, uint8_t *Mask_out,
@@ -810,20 +853,23 @@ static int segment_merge_claim_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block
     if (!ctx || !pose_block_dev || !NMap_seg || !VMap_pred || !Label || !Label_swap || Label == Label_swap || !Equations_dev)
         return RGBDSLAM_E_ARG;
     if (!RGBD_in || !Mask_in || !depth || !RGB || !RGBD_out || !Mask_out || !VMap_out || !NMap_out) return RGBDSLAM_E_ARG;
-    if (!MaskTab || !ParamTab || !ClaimTab || stamp == 0 || N_prim <= 0 || M_prim <= 0) return RGBDSLAM_E_ARG;
+    // all three tables NULL: no claim pass (a tracker that holds the plane EQUATIONS but not the Bump images, e.g. the
+    // tracking rank of the plane-partitioned form); otherwise all three and a stamp
+    const bool no_claim = !MaskTab && !ParamTab && !ClaimTab;
+    if (!no_claim && (!MaskTab || !ParamTab || !ClaimTab || stamp == 0 || N_prim <= 0 || M_prim <= 0)) return RGBDSLAM_E_ARG;
     if (RGBD_in == RGBD_out || Mask_in == Mask_out || NMap_seg == NMap_out || VMap_pred == VMap_out) return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || depth_pitch < 2 * (size_t)m) return RGBDSLAM_E_ARG;
-    if (nbPlans <= 0 || nbPlans > 255) return RGBDSLAM_E_LIMIT;
+    if (nbPlans <= 0 || nbPlans > (sizeof(LT) == 2 ? 65535 : 255)) return RGBDSLAM_E_LIMIT;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;                   // 23-bit pixel index in the claim key
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    SegArgs p1 = {pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, epsilon, alpha, n, m, 1};   // NMap_seg: scratch
-    SegArgs p2 = p1, p3 = p1;
+    SegArgsT<LT> p1 = {pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, epsilon, alpha, n, m, 1};   // NMap_seg: scratch
+    SegArgsT<LT> p2 = p1, p3 = p1;
     p2.in = Label_swap; p2.out = Label;
-    MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
+    MergeClaimArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
     MergeArgs mg = {pose_block_dev, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, ctx->calib, none, n, m};
-    MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, nullptr, stamp, N_prim, M_prim, plane_lo, plane_hi};
+    MergeClaimArgs ca = {ParamTab, MaskTab, (unsigned long long *const *)ClaimTab, nullptr, nullptr, stamp, N_prim, M_prim, plane_lo, plane_hi};
     if (ctx->seg3_fused) {                                       // labels: Label -> Label_swap, as after the three passes
-        SegArgs s3 = p1;
+        SegArgsT<LT> s3 = p1;
         s3.nb_eq = nbPlans;
         mg.ca = ca;
         dim3 g2 = grid2d(n, m);
@@ -831,15 +877,16 @@ static int segment_merge_claim_impl(rgbdslam_ctx *ctx, const rgbdslam_pose_block
         g2.y = (unsigned)(next ? 3 * (rows2 / 2) : rows2);
         PreprocessArgs pp = {};
         if (next) pp = *next;
-        KLAUNCH(ctx, k_segment3_merge_claim, g2, block2d(), s3, mg, pp, rows2);
+        KLAUNCH_AS(ctx, "k_segment3_merge_claim", (k_segment3_merge_claim<LT>), g2, block2d(), s3, mg, pp, rows2);
         HIP_TRY(hipGetLastError());
         return 0;
     }
     dim3 grid2 = grid2d(n, m);
     grid2.y *= 2;
-    KLAUNCH(ctx, k_normal_segment_merge, grid2, block2d(), p1, mg);
-    KLAUNCH(ctx, k_segment_pass_pb, grid2d(n, m), block2d(), p2);
-    KLAUNCH(ctx, k_segment_pass_claim, grid2d(n, m), block2d(), p3, ca, (const float *)VMap_out, (const uint8_t *)Mask_out);
+    KLAUNCH_AS(ctx, "k_normal_segment_merge", (k_normal_segment_merge<LT>), grid2, block2d(), p1, mg);
+    KLAUNCH_AS(ctx, "k_segment_pass_pb", (k_segment_pass_pb<LT>), grid2d(n, m), block2d(), p2);
+    KLAUNCH_AS(ctx, "k_segment_pass_claim", (k_segment_pass_claim<LT>), grid2d(n, m), block2d(), p3, ca, (const float *)VMap_out,
+               (const uint8_t *)Mask_out);
     if (next) KLAUNCH(ctx, k_frame_preprocess, grid2d(n, m), block2d(), *next);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -852,6 +899,10 @@ extern "C" int rgbdslam_model_segment_merge_claim(rgbdslam_ctx *ctx, const rgbds
                                                   float *VMap_out, float *NMap_out, uint8_t **MaskTab, float **ParamTab,
                                                   uint64_t **ClaimTab, uint32_t stamp, int N_prim, int M_prim, int n, int m,
                                                   int plane_lo, int plane_hi) {
+    if (ctx && labels16(ctx))
+        return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, (uint16_t *)Label, (uint16_t *)Label_swap, Equations_dev,
+                                        nbPlans, epsilon, alpha, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out,
+                                        NMap_out, MaskTab, ParamTab, ClaimTab, stamp, N_prim, M_prim, n, m, plane_lo, plane_hi, nullptr);
     return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, nbPlans, epsilon, alpha,
                                     RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, MaskTab, ParamTab,
                                     ClaimTab, stamp, N_prim, M_prim, n, m, plane_lo, plane_hi, nullptr);
@@ -869,6 +920,10 @@ extern "C" int rgbdslam_model_segment_merge_claim_preprocess(
         return RGBDSLAM_E_ARG;
     if (fRGB == RGB || fVMap == VMap_pred || fVMap == VMap_out || fNMap == NMap_out || fNMap == NMap_seg) return RGBDSLAM_E_ARG;
     PreprocessArgs pp = {next_depth, next_depth_pitch, next_bgr, next_bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    if (labels16(ctx))
+        return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, (uint16_t *)Label, (uint16_t *)Label_swap, Equations_dev,
+                                        nbPlans, epsilon, alpha, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out,
+                                        NMap_out, MaskTab, ParamTab, ClaimTab, stamp, N_prim, M_prim, n, m, plane_lo, plane_hi, &pp);
     return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, Label, Label_swap, Equations_dev, nbPlans, epsilon, alpha,
                                     RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out, NMap_out, MaskTab, ParamTab,
                                     ClaimTab, stamp, N_prim, M_prim, n, m, plane_lo, plane_hi, &pp);

@@ -161,6 +161,7 @@ static int launch_update(rgbdslam_ctx *ctx, const rgbdslam_pose_block *pb, const
         return RGBDSLAM_E_ARG;
     if (n <= 0 || m <= 0 || N_prim <= 0 || M_prim <= 0 || stamp == 0) return RGBDSLAM_E_ARG;
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;   // 23-bit pixel index in the claim key
+    if (Label && labels16(ctx)) { Label16 = (const uint16_t *)Label; Label = nullptr; }   // rgbdslam_set_label_width(ctx, 2)
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = pose ? pose[k] : 0.0f;
     UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, Label16, P, pb, hist,
@@ -199,8 +200,9 @@ extern "C" int rgbdslam_update_apply_tracked(rgbdslam_ctx *ctx, const rgbdslam_p
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, P, pb, nullptr,
-                    N_prim, M_prim, n, m, plane_lo, plane_hi};
+    const bool l16 = labels16(ctx);
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, l16 ? nullptr : Label,
+                    l16 ? (const uint16_t *)Label : nullptr, P, pb, nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi};
     KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -219,8 +221,9 @@ extern "C" int rgbdslam_update_apply_from_history(rgbdslam_ctx *ctx, const float
     if ((size_t)n * m > 0x7FFFFFu) return RGBDSLAM_E_LIMIT;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, P, nullptr,
-                    history_entry_dev, N_prim, M_prim, n, m, plane_lo, plane_hi};
+    const bool l16 = labels16(ctx);
+    UpdateArgs a = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, l16 ? nullptr : Label,
+                    l16 ? (const uint16_t *)Label : nullptr, P, nullptr, history_entry_dev, N_prim, M_prim, n, m, plane_lo, plane_hi};
     KLAUNCH(ctx, k_update<true>, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -243,8 +246,9 @@ extern "C" int rgbdslam_update_apply_tracked_preprocess(rgbdslam_ctx *ctx, const
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
     PoseV P;
     for (int k = 0; k < 16; k++) P.v[k] = 0.0f;
-    UpdateArgs u = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, Label, nullptr, P, pb, nullptr,
-                    N_prim, M_prim, n, m, plane_lo, plane_hi};
+    const bool l16 = labels16(ctx);
+    UpdateArgs u = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, l16 ? nullptr : Label,
+                    l16 ? (const uint16_t *)Label : nullptr, P, pb, nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi};
     PreprocessArgs p = {next_depth, depth_pitch, next_bgr, bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
     dim3 grid = grid2d(n, m);
     const int gy_update = (int)grid.y;
@@ -289,11 +293,17 @@ extern "C" int rgbdslam_update_from_history_l16(rgbdslam_ctx *ctx, const float *
 // (Frame.cpp:300-333) VMap is VertexMapGL(RGBD.w) (Kernel.cu:54-72) and RGBD.rgb is the frame's byte / 255 (Kernel.cu:463-465):
 // k_export_thin recovers the byte (rn(255 x) inverts x = b / 255 exactly), the update kernels rebuild both from the thin
 // fields with the reference's own operations.
+// Label16 / hist may be null (round 3: the label image the tracker maintains and the frame's 64-byte history entry travel in the
+// same launch instead of two stream-ordered copies of their own)
 __global__ void k_export_thin(const float *__restrict__ RGBD, const uint8_t *__restrict__ Mask, float *__restrict__ W,
-                              uint8_t *__restrict__ RGB8, uint8_t *__restrict__ MaskOut, int n, int m) {
+                              uint8_t *__restrict__ RGB8, uint8_t *__restrict__ MaskOut, const uint16_t *__restrict__ Label16,
+                              uint16_t *__restrict__ Label16Out, const float *__restrict__ hist, float *__restrict__ histOut,
+                              int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (hist && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0 && threadIdx.x < 16) histOut[threadIdx.x] = hist[threadIdx.x];
     if (i >= n || j >= m) return;
     const size_t idx = (size_t)i * m + j;
+    if (Label16) Label16Out[idx] = Label16[idx];
     const float4 v = *(const float4 *)(RGBD + 4 * idx);
     W[idx] = v.w;
     RGB8[3 * idx] = (uint8_t)f2i_rn((float)((double)v.x * 255.0));
@@ -304,7 +314,19 @@ __global__ void k_export_thin(const float *__restrict__ RGBD, const uint8_t *__r
 extern "C" int rgbdslam_export_thin(rgbdslam_ctx *ctx, const float *RGBD, const uint8_t *Mask, float *W_out, uint8_t *RGB8_out,
                                     uint8_t *Mask_out, int n, int m) {
     if (!ctx || !RGBD || !Mask || !W_out || !RGB8_out || !Mask_out || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
-    KLAUNCH(ctx, k_export_thin, grid2d(n, m), block2d(), RGBD, Mask, W_out, RGB8_out, Mask_out, n, m);
+    KLAUNCH(ctx, k_export_thin, grid2d(n, m), block2d(), RGBD, Mask, W_out, RGB8_out, Mask_out, (const uint16_t *)nullptr, (uint16_t *)nullptr,
+            (const float *)nullptr, (float *)nullptr, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// the same + the frame's u16 label image and its 64-byte history entry (either pair may be NULL), all in the one launch
+extern "C" int rgbdslam_export_thin_l16(rgbdslam_ctx *ctx, const float *RGBD, const uint8_t *Mask, const uint16_t *Label16,
+                                        const float *history_entry_dev, float *W_out, uint8_t *RGB8_out, uint8_t *Mask_out,
+                                        uint16_t *Label16_out, float *history_entry_out, int n, int m) {
+    if (!ctx || !RGBD || !Mask || !W_out || !RGB8_out || !Mask_out || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    if ((Label16 == nullptr) != (Label16_out == nullptr) || (history_entry_dev == nullptr) != (history_entry_out == nullptr)) return RGBDSLAM_E_ARG;
+    KLAUNCH(ctx, k_export_thin, grid2d(n, m), block2d(), RGBD, Mask, W_out, RGB8_out, Mask_out, Label16, Label16_out, history_entry_dev,
+            history_entry_out, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }

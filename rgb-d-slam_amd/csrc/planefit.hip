@@ -271,12 +271,13 @@ __global__ void k_fit_finish(float *__restrict__ rec, const FitState *__restrict
 }
 
 // RG.cpp:590: the blob's pixels take the plane's label; label_of_slot[s] = 0 for blobs that were not accepted
-__global__ void k_fit_labels(uint8_t *__restrict__ Label, const int32_t *__restrict__ blob, const int32_t *__restrict__ root_slot,
+template <typename LT>
+__global__ void k_fit_labels(LT *__restrict__ Label, const int32_t *__restrict__ blob, const int32_t *__restrict__ root_slot,
                              const uint8_t *__restrict__ label_of_slot, int P) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const int r = blob[p];
-    uint8_t out = 0;
+    LT out = 0;
     if (r >= 0) {
         const int s = root_slot[r];
         if (s >= 0) out = label_of_slot[s];
@@ -356,8 +357,12 @@ extern "C" int rgbdslam_fit_planes_label(rgbdslam_ctx *ctx, uint8_t *Label, cons
     char *ws = (char *)workspace;
     HIP_TRY(hipMemcpyAsync(ws + FIT_OFF_LABELS, label_of_slot_host, FIT_MAX_BLOBS, hipMemcpyHostToDevice, ctx->stream));
     const int P = n * m;
-    KLAUNCH(ctx, k_fit_labels, dim3((unsigned)((P + 255) / 256)), dim3(256), Label, blob, (const int32_t *)(ws + FIT_OFF_SLOT),
-            (const uint8_t *)(ws + FIT_OFF_LABELS), P);
+    if (labels16(ctx))                                          // rgbdslam_set_label_width(ctx, 2): Label is a u16 image
+        KLAUNCH_AS(ctx, "k_fit_labels", (k_fit_labels<uint16_t>), dim3((unsigned)((P + 255) / 256)), dim3(256), (uint16_t *)Label, blob,
+                   (const int32_t *)(ws + FIT_OFF_SLOT), (const uint8_t *)(ws + FIT_OFF_LABELS), P);
+    else
+        KLAUNCH_AS(ctx, "k_fit_labels", (k_fit_labels<uint8_t>), dim3((unsigned)((P + 255) / 256)), dim3(256), Label, blob,
+                   (const int32_t *)(ws + FIT_OFF_SLOT), (const uint8_t *)(ws + FIT_OFF_LABELS), P);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -88,44 +88,48 @@ __global__ void k_read_frame(float *__restrict__ VMap, float *__restrict__ RGBD,
 }
 
 // ---- D1/Kernel.cu:634-667 ProjectMaskKernel -------------------------------------------------------
-__global__ void k_project_mask(PoseV P, CalibV c, const uint8_t *__restrict__ mask, uint8_t *__restrict__ mask_swap,
+// T = uint8_t (Mask, Label as in the reference) or uint16_t (16-bit label images)
+template <typename T>
+__global__ void k_project_mask(PoseV P, CalibV c, const T *__restrict__ mask, T *__restrict__ mask_swap,
                                const float *__restrict__ VMap, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
     long src = project_source(P.v, c, ld3(VMap, idx), n, m);
-    mask_swap[idx] = (src < 0) ? (uint8_t)0 : mask[src];
+    mask_swap[idx] = (src < 0) ? (T)0 : mask[src];
 }
 
 // ---- D1/RG.cu:252-320 SegmentKernel, one double-buffered pass --------------------------------------
-__global__ void k_segment_pass(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const float *__restrict__ VMap,
+template <typename LT>
+__global__ void k_segment_pass(const LT *__restrict__ in, LT *__restrict__ out, const float *__restrict__ VMap,
                                const float *__restrict__ NMap, PoseV P, const float *__restrict__ Eq, float epsilon,
                                float alpha, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
-    uint8_t mine = in[idx];
+    LT mine = in[idx];
     if (mine > 0) { out[idx] = mine; return; }
     out[idx] = segment_pixel(in, VMap, ld3(NMap, idx), P.v, Eq, epsilon, alpha, i, j, n, m);
 }
 
 // plane-membership labelling (test-harness stand-in for plane detection)
-__global__ void k_seed_labels(uint8_t *__restrict__ Label, const float *__restrict__ VMap, const float *__restrict__ NMap,
+template <typename LT>
+__global__ void k_seed_labels(LT *__restrict__ Label, const float *__restrict__ VMap, const float *__restrict__ NMap,
                               PoseV P, const float *__restrict__ Eq, int nb, float epsilon, float alpha, int n, int m) {
     int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
     if (i >= n || j >= m) return;
     size_t idx = (size_t)i * m + j;
-    uint8_t res = 0;
+    LT res = 0;
     F3 nl = ld3(NMap, idx);
     if (!is_zero3(nl)) {
         F3 p = xf_point(P.v, ld3(VMap, idx));
         F3 q = xf_dir(P.v, nl);
-        for (int k = 0; k < nb && k < 255; k++) {
+        for (int k = 0; k < nb && k < (sizeof(LT) == 2 ? 65535 : 255); k++) {
             const float *E = Eq + 10 * k;
             float ed = ((p.x * E[0] + p.y * E[1]) + p.z * E[2]) - E[9];
             float ea = (q.x * E[0] + q.y * E[1]) + q.z * E[2];
             if (__builtin_fabsf(ed) > epsilon || ea < alpha) continue;
-            res = (uint8_t)(k + 1);
+            res = (LT)(k + 1);
             break;
         }
     }
@@ -222,31 +226,51 @@ extern "C" int rgbdslam_read_frame(rgbdslam_ctx *ctx, float *VMap, float *RGBD, 
 extern "C" int rgbdslam_project_mask(rgbdslam_ctx *ctx, const uint8_t *mask, uint8_t *mask_swap, const float *VMap, int n, int m) {
     if (!ctx || !mask || !mask_swap || mask == mask_swap || !VMap || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    KLAUNCH(ctx, k_project_mask, grid2d(n, m), block2d(), ctx->pose, ctx->calib, mask, mask_swap, VMap, n, m);
+    KLAUNCH_AS(ctx, "k_project_mask", (k_project_mask<uint8_t>), grid2d(n, m), block2d(), ctx->pose, ctx->calib, mask, mask_swap, VMap, n, m);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+// ProjectMask_cu on the LABEL image (Frame.cpp:389): the same gather with the context's label width
+extern "C" int rgbdslam_project_label(rgbdslam_ctx *ctx, const uint8_t *Label, uint8_t *Label_swap, const float *VMap, int n, int m) {
+    if (!ctx || !Label || !Label_swap || Label == Label_swap || !VMap || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    if (!ctx->have_calib) return RGBDSLAM_E_STATE;
+    if (!labels16(ctx)) return rgbdslam_project_mask(ctx, Label, Label_swap, VMap, n, m);
+    KLAUNCH_AS(ctx, "k_project_mask", (k_project_mask<uint16_t>), grid2d(n, m), block2d(), ctx->pose, ctx->calib, (const uint16_t *)Label,
+               (uint16_t *)Label_swap, VMap, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <typename LT>
+static int segment_impl(rgbdslam_ctx *ctx, LT *Label, LT *Label_swap, const float *VMap, const float *NMap, const float *pose,
+                        const float *Eq, float epsilon, float alpha, int n, int m) {
+    PoseV P = pose_from_host(pose);
+    LT *a = Label, *b = Label_swap;
+    for (int pass = 0; pass < 3; pass++) {                      // D1/RG.cu:910-911
+        KLAUNCH_AS(ctx, "k_segment_pass", (k_segment_pass<LT>), grid2d(n, m), block2d(), (const LT *)a, b, VMap, NMap, P, Eq, epsilon, alpha, n, m);
+        LT *t = a; a = b; b = t;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(Label, Label_swap, sizeof(LT) * (size_t)n * m, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 extern "C" int rgbdslam_segment(rgbdslam_ctx *ctx, uint8_t *Label, uint8_t *Label_swap, const float *VMap, const float *NMap,
                                 const float *pose, const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
     if (!ctx || !Label || !Label_swap || Label == Label_swap || !VMap || !NMap || !pose || !Eq || n <= 0 || m <= 0)
         return RGBDSLAM_E_ARG;
-    if (nbPlans <= 0 || nbPlans > 255) return RGBDSLAM_E_LIMIT;
-    PoseV P = pose_from_host(pose);
-    uint8_t *a = Label, *b = Label_swap;
-    for (int pass = 0; pass < 3; pass++) {                      // D1/RG.cu:910-911
-        KLAUNCH(ctx, k_segment_pass, grid2d(n, m), block2d(), a, b, VMap, NMap, P, Eq, epsilon, alpha, n, m);
-        uint8_t *t = a; a = b; b = t;
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(Label, Label_swap, (size_t)n * m, hipMemcpyDeviceToDevice, ctx->stream));
-    return 0;
+    if (nbPlans <= 0 || nbPlans > max_label(ctx)) return RGBDSLAM_E_LIMIT;
+    if (labels16(ctx)) return segment_impl(ctx, (uint16_t *)Label, (uint16_t *)Label_swap, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
+    return segment_impl(ctx, Label, Label_swap, VMap, NMap, pose, Eq, epsilon, alpha, n, m);
 }
 extern "C" int rgbdslam_seed_labels(rgbdslam_ctx *ctx, uint8_t *Label, const float *VMap, const float *NMap, const float *pose,
                                     const float *Eq, int nbPlans, float epsilon, float alpha, int n, int m) {
     if (!ctx || !Label || !VMap || !NMap || !pose || !Eq || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
-    if (nbPlans <= 0 || nbPlans > 255) return RGBDSLAM_E_LIMIT;
-    KLAUNCH(ctx, k_seed_labels, grid2d(n, m), block2d(), Label, VMap, NMap, pose_from_host(pose), Eq,
-                       nbPlans, epsilon, alpha, n, m);
+    if (nbPlans <= 0 || nbPlans > max_label(ctx)) return RGBDSLAM_E_LIMIT;
+    if (labels16(ctx))
+        KLAUNCH_AS(ctx, "k_seed_labels", (k_seed_labels<uint16_t>), grid2d(n, m), block2d(), (uint16_t *)Label, VMap, NMap,
+                   pose_from_host(pose), Eq, nbPlans, epsilon, alpha, n, m);
+    else
+        KLAUNCH_AS(ctx, "k_seed_labels", (k_seed_labels<uint8_t>), grid2d(n, m), block2d(), Label, VMap, NMap, pose_from_host(pose), Eq,
+                   nbPlans, epsilon, alpha, n, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }

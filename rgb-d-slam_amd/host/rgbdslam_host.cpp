@@ -377,6 +377,16 @@ PredictedFrame::PredictedFrame(rgbdslam_ctx *ctx, int n, int m) : _n(n), _m(m), 
     check(rgbdslam_raster_clear(ctx, _zbuf.p, n, m), "raster_clear");
 }
 
+// 16-bit label images (models of more than 255 planes; the reference's are unsigned char, Frame.h:197): the context reads
+// and writes every label image with that width from here on; the two images start again at zero
+void PredictedFrame::SetLabelWidth(int bytes) {
+    check(rgbdslam_set_label_width(_ctx, bytes), "set_label_width");
+    _label_width = bytes;
+    const size_t P = (size_t)_n * _m;
+    _label_a.alloc(P * (size_t)bytes); _label_b.alloc(P * (size_t)bytes);
+    _Label_dev = _label_a.p; _Label_dev_swap = _label_b.p;
+}
+
 void PredictedFrame::Transform(float *pose, bool quad) {
     check(rgbdslam_set_pose_matrix(_ctx, pose), "SetPoseMatrix");                                           // Frame.cpp:283
     check(rgbdslam_transform_vertex_map(_ctx, _VMap_dev.p, _RGB_dev.p, _n, _m), "TransformVertexMap");      // :290
@@ -423,7 +433,7 @@ void PredictedFrame::ProjectMask(float *pose) {
 
 void PredictedFrame::ProjectLabel(float *pose_loc, float *pose_glob, float *Equations_dev, int nbPlans) {
     check(rgbdslam_set_pose_matrix(_ctx, pose_loc), "SetPoseMatrix");
-    check(rgbdslam_project_mask(_ctx, _Label_dev, _Label_dev_swap, _VMap_dev.p, _n, _m), "ProjectMask_cu"); // Frame.cpp:389
+    check(rgbdslam_project_label(_ctx, _Label_dev, _Label_dev_swap, _VMap_dev.p, _n, _m), "ProjectMask_cu"); // Frame.cpp:389
     uint8_t *tmp = _Label_dev; _Label_dev = _Label_dev_swap; _Label_dev_swap = tmp;
     // Segment_cu with nbPlans == 0 launches kernels that can never relabel anything (no labels
     // exist before the first detection); skipped.
@@ -896,7 +906,54 @@ bool RG::AlignFrameGaussNewton() {
     return true;
 }
 
+// Label images as u16 instead of the reference's unsigned char (Frame.h:197), so that a model of more than 255 planes is
+// tracked end to end (ProjectLabel, Segment, Graph::Update).  Before the first frame, or at least before any plane exists.
+void RG::SetLabel16(bool on) {
+    if (_nbPlan != 0 || !_graph->_nodes.empty()) throw Error("SetLabel16: the label width cannot change while planes exist", RGBDSLAM_E_STATE);
+    if (fused && frames_done) Sync();
+    SyncAll();
+    _predicted_frame->SetLabelWidth(on ? 2 : 1);
+}
+
+// A tracker that maintains the LABELS of a model whose Bump images live elsewhere (the tracking rank of the plane-partitioned
+// form): the plane equations (n, e1, e2, d) x nbPlan for ProjectLabel + Segment_cu (Frame.cpp:385-405), no
+// Primitives, no Graph::Update here.  The labels of the current model frame are seeded by the caller (SeedLabelsTiled).
+void RG::SetPlaneEquations(const float *equations, int nbPlan) {
+    if (nbPlan <= 0 || nbPlan > (_predicted_frame->label_width() == 2 ? 65535 : 255))
+        throw Error("SetPlaneEquations: plane count beyond the label width", RGBDSLAM_E_LIMIT);
+    if (fused && frames_done) Sync();
+    SyncAll();
+    _graph->Clear();
+    _Equations.assign(equations, equations + 10 * (size_t)nbPlan);
+    _Centers.assign(3 * (size_t)nbPlan, 0.0f);
+    _nbPlan = nbPlan;
+    _Equations_dev.alloc(10 * (size_t)nbPlan, false);
+    hip_check(hipMemcpy(_Equations_dev.p, _Equations.data(), 40 * (size_t)nbPlan, hipMemcpyHostToDevice), "Equations");
+    _equations_only = true;
+}
+// Stand-in for plane detection on a TILED model (16-bit labels): every pixel of the current model frame takes the first plane
+// whose equation it satisfies and whose N_prim x M_prim Bump image contains its cell (rgbdslam_label_planes_l16), posed by
+// the current global pose.  From then on the labels are maintained by ProjectLabel + Segment like any others.
+void RG::SeedLabelsTiled(float **ParamTab_dev, int nbPlan, int N_prim, int M_prim) {
+    if (_predicted_frame->label_width() != 2) throw Error("SeedLabelsTiled needs 16-bit labels (SetLabel16)", RGBDSLAM_E_STATE);
+    if (fused && frames_done) Sync();
+    SyncAll();
+    float pose[16];
+    pack_pose(_poseR, _poset, pose);
+    check(rgbdslam_label_planes_l16(_ctx, (uint16_t *)_predicted_frame->_Label_dev, _predicted_frame->getVMap(), _predicted_frame->getNMap(),
+                                    pose, nullptr, ParamTab_dev, nbPlan, N_prim, M_prim, 0.1f, 0.8f, _predicted_frame->_n,
+                                    _predicted_frame->_m), "label_planes_l16");
+}
+// the label image of the frame just processed, into a frame pack (stream-ordered copy)
+void RG::ExportLabels(void *dst_dev, size_t off_label) {
+    if (!dst_dev || frames_done == 0) throw Error("ExportLabels: no frame processed yet", RGBDSLAM_E_STATE);
+    const size_t P = (size_t)_predicted_frame->_n * _predicted_frame->_m;
+    hip_check(hipMemcpyAsync((char *)dst_dev + off_label, _predicted_frame->_Label_dev, P * (size_t)_predicted_frame->label_width(),
+                             hipMemcpyDeviceToDevice, ctx_stream(_ctx)), "export labels");
+}
+
 void RG::SetPlanes(const float *equations, const float *centers, int nbPlan) {
+    _equations_only = false;
     if (fused && frames_done) Sync();
     SyncAll();
     _graph->Clear();
@@ -931,12 +988,13 @@ void RG::DetectPrimitives(float *pose) {
     if (_blob_dev.count != P) {
         _blob_dev.alloc(P, false); _blob_sizes_dev.alloc(P, false); _detect_labels.alloc(3 * P, false); _detect_bytes.alloc(8 * P, false);
     }
-    hip_check(hipMemsetAsync(_predicted_frame->_Label_dev, 0, P, s), "memset label");                      // RG.cpp:313
+    const size_t LW = (size_t)_predicted_frame->label_width();
+    hip_check(hipMemsetAsync(_predicted_frame->_Label_dev, 0, P * LW, s), "memset label");                 // RG.cpp:313
     check(rgbdslam_detect_regions(_ctx, _predicted_frame->getNMap(), _predicted_frame->getVMap(), nullptr, 120.0, 30.0, 0.03f, 20,
                                   _blob_dev.p, _blob_sizes_dev.p, _detect_labels.p, _detect_bytes.p, n, m), "detect_regions");
     _nbPlan = 0;                                                                      // RG.cpp:401
     _Equations.clear(); _Centers.clear();
-    const int max_labels = 255;
+    const int max_labels = LW == 2 ? 65535 : 255;
     // The median fit on the device (rgbdslam_fit_planes: radix select over the image instead of four downloads and three
     // sorts per blob): only 80 bytes per blob come back.  Blob order, plane numbers and the 255 cap are applied here, in
     // FindBlobs' order (ascending first pixel).  More blobs than the device path holds, or RGBDSLAM_HOST_FIT=1: the host fit below.
@@ -975,7 +1033,7 @@ void RG::DetectPrimitives(float *pose) {
     StageTimer *st_dl = new StageTimer("  regions + 4 downloads");
     std::vector<int32_t> blob(P), sizes(P);
     std::vector<float> VMap_cpu(3 * P), NMap_cpu(3 * P);                              // RG.cpp:394-396
-    std::vector<uint8_t> Label_cpu(P, 0);
+    std::vector<uint16_t> Label_cpu(P, 0);
     hip_check(hipMemcpyAsync(blob.data(), _blob_dev.p, 4 * P, hipMemcpyDeviceToHost, s), "blob download");
     hip_check(hipMemcpyAsync(sizes.data(), _blob_sizes_dev.p, 4 * P, hipMemcpyDeviceToHost, s), "sizes download");
     hip_check(hipMemcpyAsync(VMap_cpu.data(), _predicted_frame->getVMap(), 12 * P, hipMemcpyDeviceToHost, s), "VMap download");
@@ -1061,13 +1119,18 @@ void RG::DetectPrimitives(float *pose) {
         if (_nbPlan >= max_labels) break;
         const BlobFit &f = fits[r];
         if (!f.accepted) continue;
-        const uint8_t label = (uint8_t)(_nbPlan + 1);
+        const uint16_t label = (uint16_t)(_nbPlan + 1);
         for (uint32_t p : f.px) Label_cpu[p] = label;
         for (int k = 0; k < 3; k++) _Centers.push_back(f.center[k]);
         _Equations.insert(_Equations.end(), f.eq, f.eq + 10);
         _nbPlan++;
     }
-    hip_check(hipMemcpy(_predicted_frame->_Label_dev, Label_cpu.data(), P, hipMemcpyHostToDevice), "label upload");   // RG.cpp:590
+    if (LW == 2) {
+        hip_check(hipMemcpy(_predicted_frame->_Label_dev, Label_cpu.data(), 2 * P, hipMemcpyHostToDevice), "label upload");
+        return;
+    }
+    std::vector<uint8_t> narrow(Label_cpu.begin(), Label_cpu.end());
+    hip_check(hipMemcpy(_predicted_frame->_Label_dev, narrow.data(), P, hipMemcpyHostToDevice), "label upload");       // RG.cpp:590
 }
 
 // RG.cpp:934-1006: planes whose label is left on at most MIN_SIZE_PLAN pixels of the model frame are dropped, the others
@@ -1254,10 +1317,21 @@ int RG::StepAsync() {
     roctxRangePush("stage 4: fusion (Segment + Merge + Graph::Update; next frame's stage 1 may ride)");
     UpdateTables upd;
     const bool claim_in_merge = !ov && _graph->begin_update(&upd);
+    // equations without Bump images (SetPlaneEquations): the same one-launch form, its claim pass switched off
+    const bool eq_only = !ov && !claim_in_merge && _equations_only && _nbPlan > 0;
+    if (eq_only) upd = UpdateTables{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0};
     // when the caller has named the next device frame, its LoadFrame (Frame.cpp:43-77) rides on a launch of this frame
-    const bool next_rides = claim_in_merge && _next_hint.valid && !ovl && _frame->has_gradients() && !_frame->bilateral();
+    const bool next_rides = (claim_in_merge || eq_only) && _next_hint.valid && !ovl && _frame->has_gradients() && !_frame->bilateral();
     bool next_done = false;
-    if (claim_in_merge && _nbPlan > 0) {
+    if (eq_only) {
+        if (next_rides) {
+            _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd, _next_hint.depth,
+                                                     _next_hint.depth_pitch, _next_hint.bgr, _next_hint.bgr_pitch);
+            next_done = true;
+        } else {
+            _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd);
+        }
+    } else if (claim_in_merge && _nbPlan > 0) {
         // Frame.cpp:242 + 395, GP-demo.cpp:249 and the claim pass of :260 in one launch
         if (next_rides && _next_on_merge) {
             _predicted_frame->SegmentMergeClaimFused(_pb_dev, _Equations_dev.p, _nbPlan, _frame, upd, _next_hint.depth,
@@ -1360,14 +1434,17 @@ void RG::ExportFrame(void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off
 
 // The thin form of ExportFrame (rgbdslam_export_thin): RGBD.w, the colour bytes and the mask -- what the plane owners cannot
 // derive -- plus the history entry; one kernel and one 64-byte copy.
-void RG::ExportFrameThin(void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist) {
+// off_label != SIZE_MAX (16-bit labels only): the label image travels too.  One launch, no stream-ordered copies.
+void RG::ExportFrameThin(void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist, size_t off_label) {
     if (!dst_dev || frames_done == 0) throw Error("ExportFrameThin: no frame processed yet", RGBDSLAM_E_STATE);
-    hipStream_t s = ctx_stream(_ctx);
+    const bool labels = off_label != (size_t)-1;
+    if (labels && _predicted_frame->label_width() != 2) throw Error("ExportFrameThin: the pack carries 16-bit labels (SetLabel16)", RGBDSLAM_E_STATE);
     char *d = (char *)dst_dev;
-    check(rgbdslam_export_thin(_ctx, _predicted_frame->getRGB(), _predicted_frame->_Mask_dev, (float *)(d + off_w), (uint8_t *)(d + off_rgb8),
-                               (uint8_t *)(d + off_mask), _predicted_frame->_n, _predicted_frame->_m), "export_thin");
-    hip_check(hipMemcpyAsync(d + off_hist, _history_dev.p + 16 * (size_t)((frames_done - 1) % HISTORY_CAP), 64, hipMemcpyDeviceToDevice, s),
-              "export history entry");
+    check(rgbdslam_export_thin_l16(_ctx, _predicted_frame->getRGB(), _predicted_frame->_Mask_dev,
+                                   labels ? (const uint16_t *)_predicted_frame->_Label_dev : nullptr,
+                                   _history_dev.p + 16 * (size_t)((frames_done - 1) % HISTORY_CAP), (float *)(d + off_w), (uint8_t *)(d + off_rgb8),
+                                   (uint8_t *)(d + off_mask), labels ? (uint16_t *)(d + off_label) : nullptr, (float *)(d + off_hist),
+                                   _predicted_frame->_n, _predicted_frame->_m), "export_thin");
 }
 
 const float *RG::history_host(int frame_index) { return _history_host + 16 * (size_t)(frame_index % HISTORY_CAP); }
@@ -1582,6 +1659,11 @@ int slamhost_rg_set_stream_events(void *rg, int on) {
     FACADE_TRY(((RG *)rg)->_frame->set_stream_events(on != 0));
     return 0;
 }
+int slamhost_rg_export_frame_thin_labels(void *rg, void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist, size_t off_label) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->ExportFrameThin(dst_dev, off_w, off_rgb8, off_mask, off_hist, off_label));
+    return 0;
+}
 int slamhost_rg_export_frame_thin(void *rg, void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist) {
     if (!rg) return RGBDSLAM_E_ARG;
     FACADE_TRY(((RG *)rg)->ExportFrameThin(dst_dev, off_w, off_rgb8, off_mask, off_hist));
@@ -1773,6 +1855,27 @@ int slamhost_rg_detect_planes(void *rg, int min_size, int min_normals, int *nb) 
 // (RG.cpp:177-187) unless slamhost_rg_set_finish_reset_without_dump allows the reset; min_size / min_normals >= 0 override
 // MIN_SIZE_PLAN / 1000 (small images)
 // optional bilateral stage of OffLineFrame::LoadFrame (Frame.cpp:50-54, commented out in the reference): default off
+// 16-bit label images through the tracker (models of more than 255 planes); before the first frame
+int slamhost_rg_set_label16(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SetLabel16(on != 0));
+    return 0;
+}
+int slamhost_rg_set_plane_equations(void *rg, const float *equations, int nb) {
+    if (!rg || !equations) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SetPlaneEquations(equations, nb));
+    return 0;
+}
+int slamhost_rg_seed_labels_tiled(void *rg, float **ParamTab_dev, int nb, int N_prim, int M_prim) {
+    if (!rg || !ParamTab_dev) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SeedLabelsTiled(ParamTab_dev, nb, N_prim, M_prim));
+    return 0;
+}
+int slamhost_rg_export_labels(void *rg, void *dst_dev, size_t off_label) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->ExportLabels(dst_dev, off_label));
+    return 0;
+}
 int slamhost_rg_set_bilateral(void *rg, int on) {
     if (!rg) return RGBDSLAM_E_ARG;
     ((RG *)rg)->_frame->EnableBilateral(on != 0);
@@ -1869,7 +1972,7 @@ int slamhost_rg_buffer(void *rgp, const char *name, void **ptr, size_t *bytes) {
     else if (s == "NMap") { *ptr = pf->getNMap(); *bytes = 12 * P; }
     else if (s == "RGBD") { *ptr = pf->getRGB(); *bytes = 16 * P; }
     else if (s == "Mask") { *ptr = pf->_Mask_dev; *bytes = P; }
-    else if (s == "Label") { *ptr = pf->_Label_dev; *bytes = P; }
+    else if (s == "Label") { *ptr = pf->_Label_dev; *bytes = P * (size_t)pf->label_width(); }
     else if (s == "history") { *ptr = rg->history_dev(); *bytes = 64 * (size_t)RG::HISTORY_CAP; }
     else if (s == "frame.VMap") { *ptr = rg->_frame->getVMap(); *bytes = 12 * P; }
     else if (s == "frame.NMap") { *ptr = rg->_frame->getNMap(); *bytes = 12 * P; }

@@ -177,6 +177,8 @@ private:
 class PredictedFrame {
 public:
     PredictedFrame(rgbdslam_ctx *ctx, int n, int m);
+    void SetLabelWidth(int bytes);                                // 1 = unsigned char (Frame.h:197), 2 = u16 (> 255 planes)
+    int label_width() const { return _label_width; }
     void Transform(float *pose, bool quad);                       // Frame.cpp:281-298
     void ReadFrame(float znear, float zfar);                      // GP-demo.cpp:98-113 + Frame.cpp:229-245
     void Merge(OffLineFrame *frame);                              // Frame.cpp:300-333
@@ -202,10 +204,11 @@ public:
     float *getNMap() { return _NMap_dev.p; }
     float *getRGB() { return _RGB_dev.p; }
     int _n, _m;
-    uint8_t *_Mask_dev, *_Mask_dev_swap, *_Label_dev, *_Label_dev_swap;
+    uint8_t *_Mask_dev, *_Mask_dev_swap, *_Label_dev, *_Label_dev_swap;   // labels: label_width() bytes per pixel
     bool use_index_buffer = false;   // true: QuadTrimFrame writes the GL_QUADS index buffer first
 private:
     rgbdslam_ctx *_ctx;
+    int _label_width = 1;
     DevBuf<float> _VMap_dev, _NMap_dev, _RGB_dev, _tex;
     DevBuf<float> _VMap_alt, _RGB_alt;   // model set B of the fused pipeline
     DevBuf<float> _NMap_seg;             // scratch of SegmentMergeClaimFused's three-launch form (RGBDSLAM_SEG3=0)
@@ -290,6 +293,11 @@ public:
     bool AlignFrameGaussNewton();                                  // RG.cpp:797-932
     // plane injection: stands in for DetectPrimitives then runs CreatePrimitives
     void SetPlanes(const float *equations, const float *centers, int nbPlan);
+    void SetLabel16(bool on);                                     // u16 label images (models of more than 255 planes)
+    // tracker of a model whose Bump images live elsewhere (plane-partitioned form): equations for ProjectLabel + Segment only
+    void SetPlaneEquations(const float *equations, int nbPlan);
+    void SeedLabelsTiled(float **ParamTab_dev, int nbPlan, int N_prim, int M_prim);   // detection stand-in for tiled models (u16)
+    void ExportLabels(void *dst_dev, size_t off_label);
     void CreatePrimitives(float *pose, bool labels_from_detection = false);   // RG.cpp:699-793
     // plane detection: RG.cpp:277-694.  The image stages run on the GPU (rgbdslam_detect_regions);
     // the median plane fit is host code as in the reference.  DetectPlanes = the first branch of RG::Finish
@@ -343,7 +351,7 @@ public:
     void ExportFrame(void *dst_dev, size_t off_vmap, size_t off_rgbd, size_t off_mask, size_t off_hist);
     // the same for the thin pack (10 B per pixel): RGBD.w, colour bytes, Mask + the history entry; VMap and RGBD.rgb are
     // functions of those (Kernel.cu:54-72, 463-465) and every plane owner rebuilds them
-    void ExportFrameThin(void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist);
+    void ExportFrameThin(void *dst_dev, size_t off_w, size_t off_rgb8, size_t off_mask, size_t off_hist, size_t off_label = (size_t)-1);
 
     OffLineFrame *_frame;
     PredictedFrame *_predicted_frame;
@@ -370,6 +378,7 @@ public:
     void FlushDeferredApply();
     std::vector<float> _Equations, _Centers;
     DevBuf<float> _Equations_dev;
+    bool _equations_only = false;                                  // SetPlaneEquations: labels are maintained, nothing is fused here
 private:
     rgbdslam_ctx *_ctx;
     float _calib[11];

@@ -173,6 +173,14 @@ def test_planes_mode_two_ranks_on_one_card_same_model_as_one_rank():
     solo = _bench(args + ["--tracker-works", "0"], world=2)
     assert solo["config"]["planes_per_rank"] == 0 and not solo["config"]["tracker_owns_planes"]
     assert (solo["model_checksum"], solo["cells_fused"], solo["prediction_checksum"]) == (one["model_checksum"], one["cells_fused"], one["prediction_checksum"])
+    # labels: the default keeps them in the tracker (u16 images through ProjectLabel + Segment_cu, seeded once); the stand-in that
+    # labels every frame afresh by plane membership fuses about the same cells (the growth passes cannot tell the patches of one
+    # wall apart at a patch border, the stand-in can) and predicts the same coverage
+    assert one["config"]["labels"] == "tracker"
+    memb = _bench(args + ["--labels", "membership"])
+    assert memb["config"]["labels"] == "membership"
+    assert abs(memb["cells_fused"] - one["cells_fused"]) < 0.02 * one["cells_fused"]
+    assert abs(memb["predicted_coverage"] - one["predicted_coverage"]) < 0.01
     for o in (one, two):
         assert o["roofline"]["kernel"] == "k_vertex_from_bump_batch" and 0.0 < o["roofline"]["frac"] < 1.0
         assert o["unit"] == "steps/s" and o["value"] > 0

@@ -675,3 +675,44 @@ def test_solve_is_insensitive_to_the_cholesky_operation_order():
         assert np.linalg.cond(A.astype(np.float64)) < 1e4
         assert 1e-3 < np.abs(x64).max() < 0.1                                # a real increment, not a converged one
         assert np.abs(x_row - x64).max() < 1e-7 and np.abs(x_col - x64).max() < 1e-7 and np.abs(x_row - x_col).max() < 1e-7
+
+
+def test_u16_label_images_give_the_labels_of_the_u8_loop(orc, synth):
+    """The oracle's 16-bit label form (the build's extension for models of more than 255 planes; the reference keeps unsigned
+    char, Frame.h:197) is the same statements on a wider element: on a model the u8 image can hold, both widths leave the same
+    labels, model maps and Bump images -- and a model whose visible planes are numbered beyond 255 keeps them."""
+    n, m = 96, 128
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(5, n, m, calib, noise_sigma=0.001)
+    eq3, c3 = synth.plane_equations()
+
+    def run(wide, eq, ce):
+        s = orc.Slam(n, m, calib, N_prim=128, M_prim=128, max_planes=len(eq))
+        s.set_finish(False)
+        if wide:
+            s.set_label16(True)
+        for f, (d, c) in enumerate(seq):
+            s.step(d, c)
+            if f == 1:
+                s.set_planes(eq, ce)
+        nb = len(eq)
+        out = (s.buffer("Label").copy(), s.buffer("Mask").copy(), s.buffer("Maskb%d" % (nb - 1)).copy(), s.buffer("Bump%d" % (nb - 1)).copy())
+        s.close()
+        return out
+    l8, m8, mb8, b8 = run(False, eq3, c3)
+    l16, m16, mb16, b16 = run(True, eq3, c3)
+    assert l8.dtype == np.uint8 and l16.dtype == np.uint16
+    assert np.array_equal(l8.astype(np.int32), l16.astype(np.int32)) and (l8 > 0).mean() > 0.5
+    assert np.array_equal(m8, m16) and np.array_equal(mb8, mb16) and np.array_equal(b8, b16) and (mb8 > 10).sum() > 50
+    # 300 planes: 297 that no pixel satisfies (pushed 0.4 m+ behind the walls), then the three walls
+    eq = np.zeros((300, 10), np.float32)
+    ce = np.zeros((300, 3), np.float32)
+    for k in range(297):
+        off = np.float32(0.4 + 0.01 * (k // 3))
+        eq[k] = eq3[k % 3]
+        eq[k, 9] += off
+        ce[k] = c3[k % 3] + off * eq3[k % 3][:3]
+    eq[297:], ce[297:] = eq3, c3
+    lw, mw, mbw, bw = run(True, eq, ce)
+    assert np.array_equal(np.where(lw > 0, lw.astype(np.int32) - 297, 0), l8.astype(np.int32))
+    assert np.array_equal(mw, m8) and np.array_equal(mbw, mb8) and np.array_equal(bw, b8)
