@@ -325,6 +325,38 @@ def test_transform_trim_raster_read(ctx, orc, pair):
     same(host(g_rgbd), rr2)
 
 
+def test_raster_large_and_small_triangles(ctx, orc, pair):
+    """The z-buffer pass steps its edge functions in 32 bits when a triangle's bounding box spans at most 64 pixels (every
+    triangle of a depth image's mesh) and in 64 bits otherwise: a surface close to the camera (quads of 30 .. 150 pixels,
+    both sides of the switch, many crossing the image border) must give the oracle's texture bit for bit."""
+    n, m = 480, 640
+    calib = pair["calib"]
+    rng = np.random.default_rng(11)
+    ii, jj = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(m, dtype=np.float32), indexing="ij")
+    # a slanted plane 0.6 .. 0.9 m away whose vertex (i, j) is the ray of pixel (40 i, 40 j) scaled up to 150 j / row: the
+    # mesh of the first rows / columns covers the whole image with quads that grow from ~30 to ~150 pixels
+    step = (30.0 + 0.25 * jj).astype(np.float32)
+    z = (0.6 + 0.0004 * jj + 0.0002 * ii).astype(np.float32)
+    u = (np.cumsum(step, axis=1) - step[:, :1] - 40.0).astype(np.float32)
+    vstep = (20.0 + 6.0 * ii).astype(np.float32)     # rows 20, 26, 32, ... pixels apart: the first few quads stay below 64 pixels
+    w = (np.cumsum(vstep, axis=0) - vstep[:1] - 30.0).astype(np.float32)
+    v = np.zeros((n, m, 3), np.float32)
+    v[..., 0] = z * (u - calib[2]) / calib[0]
+    v[..., 1] = z * (w - calib[3]) / calib[1]
+    v[..., 2] = -z
+    rgbd = rng.random((n, m, 4)).astype(np.float32)
+    rgbd[..., 3] = z / 100.0
+    g_v, g_rgbd = dev(v), dev(rgbd)
+    zbuf = torch.empty(n, m, dtype=torch.int64, device="cuda")
+    tex = torch.empty(n, m, 4, device="cuda")
+    ctx.raster_clear(zbuf, n, m)
+    ctx.predict_raster(tex, zbuf, g_v, g_rgbd, None, n, m, thresh=10.0)
+    r_tex, _ = orc.raster(v, rgbd, calib, thresh=10.0)
+    same(host(tex), r_tex)
+    assert (r_tex[..., 3] > 0).mean() > 0.8
+    assert (host(zbuf) == -1).all()
+
+
 def test_project_mask_and_segment(ctx, orc, pair, synth):
     n, m = 480, 640
     calib = pair["calib"]
