@@ -47,9 +47,18 @@ __device__ __forceinline__ F3 normal_from_cross(F3 p, F3 dn, F3 up, F3 rt, F3 lf
     tot += tri_normal(p, lf, dn, n4);
     if (tot == 0) return z;
     float ft = (float)tot;
-    float a0 = (((n1.x + n2.x) + n3.x) + n4.x) / ft;
-    float a1 = (((n1.y + n2.y) + n3.y) + n4.y) / ft;
-    float a2 = (((n1.z + n2.z) + n3.z) + n4.z) / ft;
+    float a0 = ((n1.x + n2.x) + n3.x) + n4.x, a1 = ((n1.y + n2.y) + n3.y) + n4.y, a2 = ((n1.z + n2.z) + n3.z) + n4.z;
+#ifdef NORMAL_DIV_COUNT                              // (A/B builds only)
+    a0 = a0 / ft; a1 = a1 / ft; a2 = a2 / ft;
+#else
+    // x / 1, x / 2, x / 4 are x * 1, x * 0.5, x * 0.25 bit for bit (both are the correctly rounded value of the same real
+    // number); only a count of 3 needs a division, and a pixel with exactly three valid triangles is rare (the rim of a
+    // hole): the three IEEE divisions (~33 instructions of a ~330-instruction normal) run only in waves that hold one.
+    const float inv = (tot == 4) ? 0.25f : ((tot == 2) ? 0.5f : 1.0f);
+    if (__ballot(tot == 3) != 0ull) {
+        a0 = (tot == 3) ? a0 / ft : a0 * inv; a1 = (tot == 3) ? a1 / ft : a1 * inv; a2 = (tot == 3) ? a2 / ft : a2 * inv;
+    } else { a0 = a0 * inv; a1 = a1 * inv; a2 = a2 * inv; }
+#endif
     float nn = __builtin_sqrtf((a0 * a0 + a1 * a1) + a2 * a2);
     if (nn == 0.0f) return z;
     F3 r;

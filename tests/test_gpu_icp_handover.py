@@ -57,6 +57,62 @@ def test_soak_2000_frames_loop_kernel_with_line_check(pkg, synth):
     assert (a[:, 12] == 1.0).all() and a[1:, 13].min() >= 3
 
 
+def test_soak_under_uneven_load_with_line_check(pkg, synth):
+    """the hand-over soak again while a SECOND stream keeps streaming large device-to-device copies (512 MiB
+    each, 2 GiB in flight per round of four) beside the loop kernel -- the CUs, the L2s and the fabric are busy with somebody
+    else's traffic, workgroups of the persistent kernel become resident late and unevenly.  Every accepted line is verified:
+    zero rejections, no give-up, and the pose history is the multi-launch path's (measured without the load), bit for bit."""
+    import threading
+    n, m, frames = 480, 640, 601
+    calib, dd, bb = _frames(synth, n, m, frames)
+    eq, centers = synth.plane_equations()
+    hist = {}
+    copies = [0]
+    for mode in ("loop+check under load", "multi-launch"):
+        rg = pkg.RG(n, m, calib)
+        rg.set_finish(False)
+        stop = threading.Event()
+        worker = None
+        if mode != "multi-launch":
+            rg.set_icp_loop(True)
+            rg.set_icp_line_check(True)
+            src = torch.ones(128 << 20, dtype=torch.float32, device="cuda")          # 512 MiB
+            dst = [torch.empty_like(src) for _ in range(4)]
+            side = torch.cuda.Stream()
+
+            def stream_copies():
+                with torch.cuda.stream(side):
+                    while not stop.is_set():
+                        for d_ in dst:
+                            d_.copy_(src, non_blocking=True)
+                        side.synchronize()
+                        copies[0] += len(dst)
+            worker = threading.Thread(target=stream_copies)
+        assert rg.run_device_sequence(dd[:1], bb[:1]) == 1
+        rg.set_planes(eq, centers)
+        if worker:
+            worker.start()
+        try:
+            tracked = 0
+            for lo in range(1, frames, 100):
+                tracked += rg.run_device_sequence(dd[lo:lo + 100], bb[lo:lo + 100])
+        finally:
+            stop.set()
+            if worker:
+                worker.join()
+        assert tracked == frames - 1, "%s: %d of %d frames tracked" % (mode, tracked, frames - 1)
+        hist[mode] = rg.history(0, frames).copy()
+        if worker:
+            assert copies[0] >= 8, "the load ran beside the frames (%d copies)" % copies[0]
+            assert rg.icp_loop_faults() == 0
+            assert rg.icp_line_rejections() == 0, "a line with current sequence words failed its integrity word"
+            del src, dst
+            torch.cuda.empty_cache()
+        rg.close()
+    a, b = hist["loop+check under load"], hist["multi-launch"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "frame %d differs" % int(np.argwhere((a != b).any(1))[0])
+
+
 def test_line_check_on_the_multi_launch_and_banded_paths(pkg, synth, orc):
     """k_icp_iter (one launch per iteration) uses the same chain lines: check on == check off == oracle."""
     n, m = 240, 320
