@@ -861,7 +861,7 @@ def main():
         import glob
         pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
         pmc = json.load(open(pmc_file))
-        t = pmc["bytes_per_launch"].get(args.kernel) or pmc["bytes_per_launch"][args.kernel + "<false>"]
+        t = next(v for k_, v in sorted(pmc["bytes_per_launch"].items()) if k_ == args.kernel or k_.startswith(args.kernel + "<false"))
         traffic = t["fetch"] + t["write"]
         traffic_source = {"file": os.path.relpath(pmc_file, ROOT), "source": pmc.get("source"),
                           "note": "counters cannot be read from inside this process: separate rocprofv3 --pmc passes of this same command, committed"}
