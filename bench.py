@@ -272,6 +272,12 @@ def run_planes(args, env):
         if first_worker >= world:
             first_worker = 0
         shard = multigpu.PlaneShard(ctx, synth.tiled_planes(planes, N), N, rank, world, first_worker=first_worker)
+        # the z-buffer merge of the prediction is a collective of the PLANE OWNERS: a tracking rank without planes has nothing
+        # to draw or resolve, and an all-reduce kernel spinning on its GPU for the workers' buffers would only sit beside its tracker
+        owners = None
+        if world > 1 and first_worker == 1:
+            owners = dist.new_group(ranks=list(range(1, world)))       # (every rank makes this call)
+        predicts = args.planes_predict and not (first_worker == 1 and rank == 0)
         thin = args.pack == "thin"
         pipelined = bool(args.pipeline)
         # tracker: the labels are maintained by the reference's own per-frame path, ProjectLabel + Segment_cu (Frame.cpp:385-405)
@@ -311,10 +317,11 @@ def run_planes(args, env):
             # The persistent ICP kernel needs every CU for itself (one workgroup per CU, all resident).  Beside the decode of
             # planes on the SAME GPU (pipelined step, tracker owning planes) it does not get them: its workgroups trickle in as
             # the decode's drain, the resident ones spin, and when the two start together the decode runs at half speed
-            # (kernel trace, profiles/r03_o_planes_trace.txt: 1 200 instead of 650 us on every third step).  There the loop runs
-            # as one launch per iteration, which interleaves; alone on its GPU (first_worker == 1) or in the serial step it
-            # is the one launch per frame.
-            loop_ok = bool(args.icp_loop) and (first_worker == 1 or not pipelined)
+            # (kernel trace, profiles/r03_o_planes_trace.txt: 1 200 instead of 650 us on every third step).  In the pipelined
+            # step the loop therefore runs as one launch per iteration, which interleaves -- also on a rank 0 without planes,
+            # where RCCL's broadcast kernel still shares the GPU with it (unrehearsed: no multi-GPU node; --icp-loop 2 forces the
+            # persistent kernel there); in the serial step it is the one launch per frame.
+            loop_ok = args.icp_loop == 2 or (bool(args.icp_loop) and not pipelined)
             icp_form = "one launch per iteration"
             if world == 1 or "RGBDSLAM_BENCH_DEVICE" not in os.environ:
                 try:
@@ -402,20 +409,20 @@ def run_planes(args, env):
                 free_recorded[b] = True
             if mark:
                 mark("w1", stream)
-            if args.planes_predict and pred_stream is not stream:
+            if predicts and pred_stream is not stream:
                 ev_fused.record(stream)
                 pred_stream.wait_event(ev_fused)
             shard.decode()
             if mark:
                 mark("w2", stream)
-            if args.planes_predict:
+            if predicts:
                 # the "raycast" half of configs[2]: the view of the frame just fused, predicted from the planes.  The view is
                 # the synthetic trajectory's pose of that frame (known to every rank without reading the tracked pose
                 # back from rank 0's device: nothing here waits for the GPU)
                 if mark:
                     mark("p0", pred_stream)
                 with torch.cuda.stream(pred_stream):
-                    shard.predict(view_w2c[order[f]], n, m, ctx=ctx_pred)
+                    shard.predict(view_w2c[order[f]], n, m, ctx=ctx_pred, group=owners)
                 if mark:
                     mark("p1", pred_stream)
                 if pred_stream is not stream:
@@ -469,7 +476,7 @@ def run_planes(args, env):
                 by.setdefault(name, []).append(e)
             span = lambda a_, b_: round(sum(by[a_][q].elapsed_time(by[b_][q]) for q in range(reps)) / reps * 1e3, 1)
             phases = {"track_label_export": span("k0", "k1"), "broadcast": span("t1", "t2"), "fuse": span("w0", "w1"), "decode": span("w1", "w2"),
-                      "predict_draw_merge_resolve": span("p0", "p1") if args.planes_predict else 0.0,
+                      "predict_draw_merge_resolve": span("p0", "p1") if predicts else 0.0,
                       "work_stream_step": round(by["w0"][0].elapsed_time(by["w3"][reps - 1]) / reps * 1e3, 1)}
             phases["unit"] = ("us per step on rank 0 (event pairs, second pass); pipelined: tracking, broadcast, fusion + decode and the "
                               "prediction each on a stream of their own, spans overlap" if pipelined else
@@ -513,8 +520,11 @@ def run_planes(args, env):
                             int((shard.mask > 10).sum())], dtype=torch.int64, device=env["coll_dev"])
         if args.planes_predict:
             # the last predicted view, summed over the ranks' disjoint outputs as integers: independent of the partition
-            pchk = int(shard.pred_v.view(torch.int32).to(torch.int64).sum()) + 3 * int(shard.pred_c.view(torch.int32).to(torch.int64).sum())
-            chk = torch.cat([chk, torch.tensor([pchk, int((shard.pred_v[..., 2] != 0).sum())], dtype=torch.int64, device=env["coll_dev"])])
+            pchk, pcov = 0, 0                        # (a tracking rank without planes predicts nothing)
+            if predicts:
+                pchk = int(shard.pred_v.view(torch.int32).to(torch.int64).sum()) + 3 * int(shard.pred_c.view(torch.int32).to(torch.int64).sum())
+                pcov = int((shard.pred_v[..., 2] != 0).sum())
+            chk = torch.cat([chk, torch.tensor([pchk, pcov], dtype=torch.int64, device=env["coll_dev"])])
         if world > 1:
             dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         cells = (shard.hi - shard.lo) * N * N
@@ -696,7 +706,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--icp-loop", type=int, default=1,
                     help="1 (default): persistent-loop ICP, one launch per frame (rgbdslam_set_icp_loop: this process owns the GPU "
-                         "and uses one stream, which is how bench.py runs); 0: twelve k_icp_iter launches per frame")
+                         "and uses one stream, which is how bench.py runs); 0: twelve k_icp_iter launches per frame; "
+                         "planes mode: the pipelined step runs the tracker's loop as one launch per iteration unless this is 2")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: next frame's preprocessing and the Bump update on auxiliary streams (RG::overlap; measured slower)")
     ap.add_argument("--finish-period", type=int, default=0,

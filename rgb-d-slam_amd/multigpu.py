@@ -301,7 +301,7 @@ class PlaneShard:
                                                  pack.ptr(pack.off_mask), pack.ptr(pack.off_label), self.N, self.N, pack.n, pack.m,
                                                  self.lo, self.hi)
 
-    def predict(self, pose_w2c16, n, m, min_conf=1, ctx=None):
+    def predict(self, pose_w2c16, n, m, min_conf=1, ctx=None, group=None):
         """Prediction of the view `pose_w2c16` (world-to-camera, column-major 4x4) from the planes, partitioned like the
         fusion: this rank draws the planes it owns into its own u64 z-buffer, ONE all-reduce(MIN) merges the ranks'
         buffers (the key is depth bits << 32 | ~triangle id: the nearest surface wins whoever drew it), and the rank
@@ -315,7 +315,7 @@ class PlaneShard:
         if self.hi > self.lo:
             ctx.planes_draw(self.zbuf, self.t_bump, self.t_rgb, self.t_mask, self.t_param, self.lo, self.hi, pose_w2c16,
                                  self.N, self.N, n, m, min_conf=min_conf)
-        allreduce_min_u64(self.zbuf)
+        allreduce_min_u64(self.zbuf, group=group)    # group: the plane owners (a tracking rank without planes stays out of it)
         self.pred_v.zero_(); self.pred_c.zero_()          # pixels other ranks' planes won stay zero here: the outputs are disjoint
         if self.hi > self.lo:
             ctx.planes_resolve(self.zbuf, self.pred_v, self.pred_c, self.t_bump, self.t_rgb, self.t_mask, self.t_param,
@@ -327,19 +327,19 @@ class PlaneShard:
 _SIGN64 = -(1 << 63)
 
 
-def allreduce_min_u64(zbuf):
+def allreduce_min_u64(zbuf, group=None):
     """Merge of the z-buffers that the ranks drew from their own planes (rgbdslam_planes_draw): elementwise UNSIGNED 64-bit
     minimum over all ranks, in place.  The key is depth bits << 32 | ~triangle id, so the minimum is the nearest surface
     whichever rank drew it.  torch has no u64 reductions: the sign bit is flipped (monotonic u64 -> i64), MIN, flipped back."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return zbuf
     z = zbuf.view(torch.int64)
     z ^= _SIGN64
     if z.is_cuda and dist.get_backend() == "gloo":
         h = z.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
         z.copy_(h)
     else:
-        dist.all_reduce(z, op=dist.ReduceOp.MIN)
+        dist.all_reduce(z, op=dist.ReduceOp.MIN, group=group)
     z ^= _SIGN64
     return zbuf
