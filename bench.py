@@ -848,6 +848,18 @@ def main():
     tot_ms, launches = C.c_double(), C.c_int()
     lib.rgbdslam_profile_read(ctx, C.byref(tot_ms), C.byref(launches))
     lib.rgbdslam_profile_kernel(ctx, None)
+    # ---- per-stage timers (the reference's TIMING switch, Utilities.h:82 / GP-demo.cpp:153-277): a pass of its own, 64 frames,
+    # HIP events at the stage boundaries (RG::SetStageTiming) -- the events cost ~2 us each, so this is not the timed region ----
+    stage_times = None
+    cont = pos if args.profile_in_timed_region else pos + args.steps
+    if len(order) >= cont + 64:
+        rg.set_stage_timing(True)
+        run(order[cont:cont + 64])
+        st_, nf_ = rg.stage_times()
+        rg.set_stage_timing(False)
+        stage_times = dict(st_, frames=nf_, unit="us per frame, HIP events at the stage boundaries in a pass of their own (event cost included: "
+                           "the sum exceeds ms_per_step); stage 1 rides on the previous frame's stage-4 launch inside a recorded sequence, "
+                           "so its own span is the two event records only")
     per_frame_launches = launches.value / float(args.steps)
     if args.kernel in ("k_icp_iter", "k_icp_loop"):
         bytes_all_frames = algo_bytes(args.kernel, n, m, per_level_total)
@@ -1011,7 +1023,7 @@ def main():
                           "rows": n, "cols": m, "sequences": world, "frames_resident_in_hbm": True,
                           "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame",
                           "finish_period": args.finish_period},
-               "parity_in_run": parity, "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
+               "parity_in_run": parity, "stage_times": stage_times, "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
         print(json.dumps(check_line(out)), flush=True)
     rg.close()
     if world > 1:

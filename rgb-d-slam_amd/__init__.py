@@ -481,6 +481,20 @@ class RG:
         _hchk(self.lib.slamhost_rg_history(self._h, int(first), int(count), C.c_void_p(out.ctypes.data)), "history")
         return out
 
+    def set_stage_timing(self, on):
+        """The reference's TIMING switch (D1/Utilities.h:82, GP-demo.cpp:153-277) for the asynchronous pipeline: HIP events at
+        the stage boundaries (an event record per boundary: opt-in)."""
+        _hchk(self.lib.slamhost_rg_set_stage_timing(self._h, int(on)), "set_stage_timing")
+
+    def stage_times(self):
+        """Mean us per frame since the last read (at most the last 64 frames) -> (dict, frames): stage 1 preprocessing (0 when
+        it rode on the previous frame's merge launch), stages 2+3 ICP, stage 5 prediction, stage 4 fusion."""
+        us = (C.c_double * 4)()
+        frames = C.c_int()
+        _hchk(self.lib.slamhost_rg_stage_times(self._h, us, C.byref(frames)), "stage_times")
+        names = ("stage1_preprocess", "stage2_3_icp", "stage5_prediction", "stage4_fusion")
+        return {k: round(us[i], 2) for i, k in enumerate(names)}, frames.value
+
     def set_label16(self, on):
         """u16 label images through the whole tracker (ProjectLabel, Segment, Graph::Update) instead of the reference's
         unsigned char (Frame.h:197): models of more than 255 planes.  Before any plane exists."""

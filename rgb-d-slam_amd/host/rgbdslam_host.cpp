@@ -709,6 +709,7 @@ RG::~RG() {
     if (_update_stream) (void)hipStreamDestroy(_update_stream);
     if (_ev_merged) (void)hipEventDestroy(_ev_merged);
     if (_ev_updated) (void)hipEventDestroy(_ev_updated);
+    for (auto &e : _stage_ev) if (e) (void)hipEventDestroy(e);
     if (_pinned) (void)hipHostFree(_pinned);
     if (_pb_dev) (void)hipFree(_pb_dev);
     if (_pb_host) (void)hipHostFree(_pb_host);
@@ -736,9 +737,54 @@ bool RG::LoadFrame(const uint16_t *depth_host, const uint8_t *bgr_host) {
 bool RG::LoadFrameDevice(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
     StageRange r("stage 1: preprocessing (OffLineFrame::LoadFrame)");
     configure_streams();
+    stage_mark(0);
     _frame->LoadFrameDevice(depth_dev, depth_pitch, bgr_dev, bgr_pitch);
+    stage_mark(1);
     _count++;
     return true;
+}
+
+// ---- per-stage timers (the reference's TIMING, Utilities.h:82 / GP-demo.cpp:153-277) ----------------------------------------
+// marks of one frame: 0 / 1 round stage 1 (LoadFrame), 2 before the tracking, 3 after it, 4 after the prediction, 5 after the fusion
+void RG::SetStageTiming(bool on) {
+    if (on && _stage_ev.empty()) {
+        _stage_ev.resize((size_t)STAGE_RING * STAGE_MARKS, nullptr);
+        _stage_set.assign((size_t)STAGE_RING, 0);
+        for (auto &e : _stage_ev) hip_check(hipEventCreate(&e), "hipEventCreate");
+    }
+    if (on && !_stage_timing) { _stage_frames = 0; std::fill(_stage_set.begin(), _stage_set.end(), 0); }
+    _stage_timing = on;
+}
+void RG::stage_mark(int mark) {
+    if (!_stage_timing) return;
+    // marks 0 / 1 belong to the frame that is being loaded (the one the next StepAsync processes), the others to that step
+    const int slot = _stage_frames % STAGE_RING;
+    hipStream_t s = (mark <= 1 && _frame->load_stream()) ? (hipStream_t)_frame->load_stream() : ctx_stream(_ctx);
+    hip_check(hipEventRecord(_stage_ev[(size_t)slot * STAGE_MARKS + mark], s), "hipEventRecord");
+    _stage_set[(size_t)slot] |= (unsigned char)(1u << mark);
+    if (mark == 5) { _stage_frames++; _stage_set[(size_t)(_stage_frames % STAGE_RING)] = 0; }   // the next frame starts clean
+}
+int RG::StageTimes(double us[4]) {
+    for (int k = 0; k < 4; k++) us[k] = 0.0;
+    if (_stage_ev.empty() || _stage_frames == 0) return 0;
+    SyncAll();
+    const int frames = std::min(_stage_frames, (int)STAGE_RING);
+    const int pairs[4][2] = {{0, 1}, {2, 3}, {3, 4}, {4, 5}};
+    for (int f = 0; f < frames; f++) {
+        const int slot = (_stage_frames - 1 - f) % STAGE_RING;
+        for (int k = 0; k < 4; k++) {
+            const unsigned need = (1u << pairs[k][0]) | (1u << pairs[k][1]);
+            if ((_stage_set[(size_t)slot] & need) != need) continue;            // (a frame loaded before the timers were on)
+            float ms = 0.0f;
+            hip_check(hipEventElapsedTime(&ms, _stage_ev[(size_t)slot * STAGE_MARKS + pairs[k][0]],
+                                          _stage_ev[(size_t)slot * STAGE_MARKS + pairs[k][1]]), "hipEventElapsedTime");
+            us[k] += 1e3 * (double)ms;
+        }
+    }
+    for (int k = 0; k < 4; k++) us[k] /= (double)frames;
+    _stage_frames = 0;
+    std::fill(_stage_set.begin(), _stage_set.end(), 0);
+    return frames;
 }
 
 void RG::HintNextDeviceFrame(const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
@@ -1298,11 +1344,13 @@ int RG::StepAsync() {
     StageRange r_frame("rgbdslam:display() pass");
     rgbdslam_icp_params prm = icp_params();
     const int slot = frames_done % HISTORY_CAP;
+    stage_mark(2);
     { StageRange r("stage 2+3: ICP + 27-term reduction (RG::AlignFrameGaussNewton)");
     check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _frame->getGx(), pitch, _frame->getGy(), pitch,
                                _predicted_frame->getVMap(), _predicted_frame->getNMap(), _predicted_frame->getRGB(), n, m, _pb_dev,
                                _history_dev.p, slot), "track_frame");               // GP-demo.cpp:189 + 201-245
     }
+    stage_mark(3);
     // the previous frame's Bump update (other stream) reads the model this frame is about to rewrite
     if (ov && _update_pending) hip_check(hipStreamWaitEvent(main, _ev_updated, 0), "wait for the previous update");
     // GP-demo.cpp:215-237 + ProjectLabel gather; if lost: Cpy + InitMask instead (GP-demo.cpp:190-191)
@@ -1314,6 +1362,7 @@ int RG::StepAsync() {
         _predicted_frame->PredictFused(_pb_dev, Znear, Zfar, _frame);
     }
     roctxRangePop();
+    stage_mark(4);
     roctxRangePush("stage 4: fusion (Segment + Merge + Graph::Update; next frame's stage 1 may ride)");
     UpdateTables upd;
     const bool claim_in_merge = !ov && _graph->begin_update(&upd);
@@ -1372,6 +1421,7 @@ int RG::StepAsync() {
         }
     }
     roctxRangePop();
+    stage_mark(5);
     _next_hint.valid = false;
     frames_done++;
     { StageRange r("RG::Finish"); Finish(); }                                       // GP-demo.cpp:274
@@ -1874,6 +1924,17 @@ int slamhost_rg_seed_labels_tiled(void *rg, float **ParamTab_dev, int nb, int N_
 int slamhost_rg_export_labels(void *rg, void *dst_dev, size_t off_label) {
     if (!rg) return RGBDSLAM_E_ARG;
     FACADE_TRY(((RG *)rg)->ExportLabels(dst_dev, off_label));
+    return 0;
+}
+// per-stage timers (the reference's TIMING switch): RG::SetStageTiming / RG::StageTimes
+int slamhost_rg_set_stage_timing(void *rg, int on) {
+    if (!rg) return RGBDSLAM_E_ARG;
+    FACADE_TRY(((RG *)rg)->SetStageTiming(on != 0));
+    return 0;
+}
+int slamhost_rg_stage_times(void *rg, double *us4, int *frames) {
+    if (!rg || !us4 || !frames) return RGBDSLAM_E_ARG;
+    FACADE_TRY(*frames = ((RG *)rg)->StageTimes(us4));
     return 0;
 }
 int slamhost_rg_set_bilateral(void *rg, int on) {

@@ -293,6 +293,13 @@ public:
     bool AlignFrameGaussNewton();                                  // RG.cpp:797-932
     // plane injection: stands in for DetectPrimitives then runs CreatePrimitives
     void SetPlanes(const float *equations, const float *centers, int nbPlan);
+    // The reference's TIMING switch (Utilities.h:82; clock() round every stage of display(), GP-demo.cpp:153-277) for an
+    // asynchronous pipeline: HIP events at the stage boundaries on the frame stream, read back on demand.  Costs an event
+    // record per boundary (~2 us each), hence opt-in.  StageTimes: mean us per frame of the frames since the last read (at
+    // most the last 64): [0] stage 1 preprocessing (0 when it rode on the previous frame's merge launch), [1] stages 2+3 ICP,
+    // [2] stage 5 prediction, [3] stage 4 fusion (Segment + Merge + Graph::Update and whatever rides on it); returns the frames.
+    void SetStageTiming(bool on);
+    int StageTimes(double us[4]);
     void SetLabel16(bool on);                                     // u16 label images (models of more than 255 planes)
     // tracker of a model whose Bump images live elsewhere (plane-partitioned form): equations for ProjectLabel + Segment only
     void SetPlaneEquations(const float *equations, int nbPlan);
@@ -385,6 +392,13 @@ private:
     DevBuf<float> _intr_dev, _Rcurr_dev, _tcurr_dev, _img1, _Gx, _Gy, _pose_state_dev, _trace_dev;
     hipStream_t _load_stream = nullptr, _update_stream = nullptr;
     hipEvent_t _ev_merged = nullptr, _ev_updated = nullptr;
+    // per-stage timers (SetStageTiming): HIP events at the stage boundaries of the last STAGE_RING frames
+    static const int STAGE_RING = 64, STAGE_MARKS = 6;
+    bool _stage_timing = false;
+    std::vector<hipEvent_t> _stage_ev;                             // [STAGE_RING][STAGE_MARKS]
+    std::vector<unsigned char> _stage_set;                         // which marks of a ring entry were recorded
+    int _stage_frames = 0;
+    void stage_mark(int mark);
     bool _update_pending = false;
     int _overlap_mode = 3;   // bit 0: loads on the load stream, bit 1: Bump update on the update stream
     bool _overlap_mode_set = false;

@@ -560,3 +560,33 @@ def test_reorganize_equa_drops_unseen_planes_and_renumbers(pkg, orc, synth):
             same(rg.buffer("%s%d" % (slab, k)), ref.buffer("%s%d" % (slab, k)), "%s%d" % (slab, k))
     rg.close()
     ref.close()
+
+
+def test_stage_timers_cover_the_frame(pkg, synth):
+    """RG::SetStageTiming (the reference's TIMING switch, Utilities.h:82 / GP-demo.cpp:153-277): HIP events at the stage boundaries;
+    the four spans are positive, the ICP is the longest, and switching the timers on changes no pose."""
+    n, m = 240, 320
+    calib = synth.calib_for(n, m)
+    seq = synth.sequence(12, n, m, calib, noise_sigma=0.001)
+    dd = [torch.from_numpy(d).cuda() for d, _ in seq]
+    bb = [torch.from_numpy(c).cuda() for _, c in seq]
+    hist = []
+    for timed in (False, True):
+        rg = pkg.RG(n, m, calib, N_prim=256, M_prim=256)
+        rg.set_finish(False)
+        if timed:
+            rg.set_stage_timing(True)
+        assert rg.run_device_sequence(dd[:1], bb[:1]) == 1
+        rg.set_planes(*synth.plane_equations())
+        for k in range(1, 12):                                   # frame by frame: stage 1 is a launch of its own
+            rg.load_frame_device(dd[k], bb[k])
+            assert rg.step() == 1
+        if timed:
+            st, frames = rg.stage_times()
+            assert frames == 12
+            assert all(st[k] > 1.0 for k in ("stage1_preprocess", "stage2_3_icp", "stage5_prediction", "stage4_fusion")), st
+            assert st["stage2_3_icp"] > st["stage5_prediction"] and st["stage2_3_icp"] > st["stage1_preprocess"]
+            assert rg.stage_times()[1] == 0                      # read and reset
+        hist.append(rg.history(0, 12).copy())
+        rg.close()
+    assert np.array_equal(hist[0].view(np.uint32), hist[1].view(np.uint32))
