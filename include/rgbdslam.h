@@ -572,6 +572,22 @@ int rgbdslam_label_planes_l16(rgbdslam_ctx *ctx, uint16_t *Label16, const float 
  * nbPlans may then reach 65535.  The *_l16 entry points above take u16 labels whatever the width.  Same kernels (templates on
  * the label type), same arithmetic: a model of at most 255 planes gives the same labels at either width. */
 int rgbdslam_set_label_width(rgbdslam_ctx *ctx, int bytes_per_label);
+/* One POD for what the reference spreads over compile-time #defines and the RG constructor's arguments (cudaTypes.cuh:41-51,
+ * Utilities.h:75-85, GP-demo.cpp:326-451: RG(n, m, path, Calib[11], lvl, distThres, angleThres, ...); RG.h:111,124-126) plus this
+ * library's own switches.  rgbdslam_config_defaults fills the reference's TUM fr1/xyz values (GP-demo.cpp:404-409);
+ * rgbdslam_configure applies calib / switches to the context (the ICP parameters are per call: pass cfg->icp to
+ * rgbdslam_track_frame / rgbdslam_align_gauss_newton); rgbdslam_get_config reads the context's current values back (icp is left
+ * untouched).  The individual setters remain. */
+typedef struct rgbdslam_config {
+    float calib[11];               /* fx fy cx cy k1..k5 ds factor (GP-demo.cpp:17,404) */
+    rgbdslam_icp_params icp;       /* lvl 3, max_iter {3,2,1}, distThres 0.05, angleThres sin 20 deg, thres_cvg 1e-6 */
+    int icp_loop;                  /* rgbdslam_set_icp_loop */
+    int icp_line_check;            /* rgbdslam_set_icp_line_check */
+    int label_width;               /* rgbdslam_set_label_width: 1 (Frame.h:197) or 2 */
+} rgbdslam_config;
+void rgbdslam_config_defaults(rgbdslam_config *cfg);
+int rgbdslam_configure(rgbdslam_ctx *ctx, const rgbdslam_config *cfg);
+int rgbdslam_get_config(const rgbdslam_ctx *ctx, rgbdslam_config *cfg);
 int rgbdslam_get_label_width(const rgbdslam_ctx *ctx);
 /* Kernel.cuh:24 ProjectMask_cu applied to the LABEL image (Frame.cpp:389, the gather of PredictedFrame::ProjectLabel):
  * rgbdslam_project_mask with the context's label width (uses the context's pose, like rgbdslam_project_mask). */

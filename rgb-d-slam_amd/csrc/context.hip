@@ -66,6 +66,34 @@ extern "C" int rgbdslam_set_label_width(rgbdslam_ctx *ctx, int bytes) {
 }
 extern "C" int rgbdslam_get_label_width(const rgbdslam_ctx *ctx) { return ctx ? ctx->label_width : RGBDSLAM_E_ARG; }
 
+// ---- one POD configuration (the reference's #defines + RG constructor arguments) ---------------------------------
+extern "C" void rgbdslam_config_defaults(rgbdslam_config *cfg) {
+    if (!cfg) return;
+    const float tum[11] = {525.0f, 525.0f, 319.5f, 239.5f, 0.2624f, -0.9531f, -0.0054f, 0.0026f, 1.1633f, 1.035f, 5000.0f};   // GP-demo.cpp:404
+    memcpy(cfg->calib, tum, sizeof(tum));
+    cfg->icp.lvl = 3;                                                        // GP-demo.cpp:409
+    cfg->icp.max_iter[0] = 3; cfg->icp.max_iter[1] = 2; cfg->icp.max_iter[2] = 1;   // RG.h:124-126
+    cfg->icp.distThres = 0.05f; cfg->icp.angleThres = 0.3420201433256687f;   // sin 20 deg, GP-demo.cpp:409
+    cfg->icp.thres_cvg_alpha = 1e-6f; cfg->icp.thres_cvg_tr = 1e-6f;         // RG.h:111
+    cfg->icp_loop = 0; cfg->icp_line_check = 0; cfg->label_width = 1;
+}
+extern "C" int rgbdslam_configure(rgbdslam_ctx *ctx, const rgbdslam_config *cfg) {
+    if (!ctx || !cfg) return RGBDSLAM_E_ARG;
+    if (cfg->label_width != 1 && cfg->label_width != 2) return RGBDSLAM_E_ARG;
+    int rc = rgbdslam_set_calibration_matrix(ctx, cfg->calib);
+    if (rc) return rc;
+    if ((rc = rgbdslam_set_label_width(ctx, cfg->label_width))) return rc;
+    if ((rc = rgbdslam_set_icp_line_check(ctx, cfg->icp_line_check))) return rc;
+    if (cfg->icp_loop != ctx->icp_loop && (rc = rgbdslam_set_icp_loop(ctx, cfg->icp_loop))) return rc;   // needs the ICP buffers (rgbdslam_alloc_buffers)
+    return 0;
+}
+extern "C" int rgbdslam_get_config(const rgbdslam_ctx *ctx, rgbdslam_config *cfg) {
+    if (!ctx || !cfg) return RGBDSLAM_E_ARG;
+    for (int k = 0; k < 11; k++) cfg->calib[k] = ctx->calib.v[k];
+    cfg->icp_loop = ctx->icp_loop; cfg->icp_line_check = ctx->icp_line_check; cfg->label_width = ctx->label_width;
+    return 0;
+}
+
 extern "C" int rgbdslam_get_stream(rgbdslam_ctx *ctx, void **stream) {
     if (!ctx || !stream) return RGBDSLAM_E_ARG;
     *stream = (void *)ctx->stream;

@@ -46,6 +46,30 @@ def test_null_arguments_are_rejected_without_a_device(pkg):
     assert lib.rgbdslam_create(null, 0, null) == 1
 
 
+def test_config_pod_defaults_are_the_reference_values(pkg):
+    """rgbdslam_config (one POD for the reference's #defines + RG constructor arguments): the defaults are the TUM fr1/xyz
+    values of D1/GP-demo.cpp:404-409 and D1/RG.h:111,124-126; the context calls reject NULL without a device."""
+    lib = pkg.load()
+
+    class IcpParams(C.Structure):
+        _fields_ = [("lvl", C.c_int), ("max_iter", C.c_int * 3), ("distThres", C.c_float), ("angleThres", C.c_float),
+                    ("thres_cvg_alpha", C.c_float), ("thres_cvg_tr", C.c_float)]
+
+    class Config(C.Structure):
+        _fields_ = [("calib", C.c_float * 11), ("icp", IcpParams), ("icp_loop", C.c_int), ("icp_line_check", C.c_int), ("label_width", C.c_int)]
+    cfg = Config()
+    lib.rgbdslam_config_defaults.restype = None
+    lib.rgbdslam_config_defaults(C.byref(cfg))
+    assert [round(x, 4) for x in cfg.calib] == [525.0, 525.0, 319.5, 239.5, 0.2624, -0.9531, -0.0054, 0.0026, 1.1633, 1.035, 5000.0]
+    assert cfg.icp.lvl == 3 and list(cfg.icp.max_iter) == [3, 2, 1]
+    assert abs(cfg.icp.distThres - 0.05) < 1e-7 and abs(cfg.icp.angleThres - np.sin(np.deg2rad(20.0))) < 1e-7
+    assert cfg.icp.thres_cvg_alpha == np.float32(1e-6) and cfg.icp.thres_cvg_tr == np.float32(1e-6)
+    assert (cfg.icp_loop, cfg.icp_line_check, cfg.label_width) == (0, 0, 1)
+    null = C.c_void_p(0)
+    assert lib.rgbdslam_configure(null, C.byref(cfg)) == 1 and lib.rgbdslam_get_config(null, C.byref(cfg)) == 1
+    assert lib.rgbdslam_set_label_width(null, 2) == 1
+
+
 def test_host_library_exports(pkg):
     host = pkg.load_host()
     for s in ["slamhost_rg_create", "slamhost_rg_destroy", "slamhost_rg_load_frame", "slamhost_rg_load_frame_device",

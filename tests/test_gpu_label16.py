@@ -176,3 +176,28 @@ def test_label_width_cannot_change_while_planes_exist(pkg, synth):
     with pytest.raises(pkg.SlamError):
         rg.set_label16(True)
     rg.close()
+
+
+def test_config_pod_round_trip(pkg):
+    """rgbdslam_configure / rgbdslam_get_config: calibration and switches of a context through one POD."""
+    import ctypes as C
+    lib = pkg.load()
+
+    class IcpParams(C.Structure):
+        _fields_ = [("lvl", C.c_int), ("max_iter", C.c_int * 3), ("distThres", C.c_float), ("angleThres", C.c_float),
+                    ("thres_cvg_alpha", C.c_float), ("thres_cvg_tr", C.c_float)]
+
+    class Config(C.Structure):
+        _fields_ = [("calib", C.c_float * 11), ("icp", IcpParams), ("icp_loop", C.c_int), ("icp_line_check", C.c_int), ("label_width", C.c_int)]
+    ctx = pkg.Context(0)
+    cfg, back = Config(), Config()
+    lib.rgbdslam_config_defaults.restype = None
+    lib.rgbdslam_config_defaults(C.byref(cfg))
+    cfg.label_width, cfg.icp_line_check = 2, 1
+    assert lib.rgbdslam_configure(ctx._h, C.byref(cfg)) == 0
+    assert lib.rgbdslam_get_config(ctx._h, C.byref(back)) == 0
+    assert list(back.calib) == list(cfg.calib) and (back.label_width, back.icp_line_check, back.icp_loop) == (2, 1, 0)
+    assert ctx.label_width() == 2
+    cfg.label_width = 3
+    assert lib.rgbdslam_configure(ctx._h, C.byref(cfg)) == 1      # RGBDSLAM_E_ARG
+    ctx.close()
