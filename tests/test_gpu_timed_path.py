@@ -94,6 +94,52 @@ def test_bench_path_640x480_matches_the_oracle(pkg, orc, synth):
 
 
 @pytest.mark.parametrize("icp_loop", [True, False])
+def test_fused_frame_kernels_1080p_match_the_oracle(pkg, orc, synth, icp_loop):
+    """bench.py's `hbm_bound_kernels` workload at BASELINE configs[3]'s frame size: 1920 x 1080, 1 mm noise, seed frame, the
+    three synthetic plane equations attached by set_planes, then the 8-frame order 1 2 3 2 1 0 1 2 in ONE recorded sequence
+    (so k_segment3_merge_claim carries the next frame's preprocessing, k_predict_draw the deferred apply pass).  The DESIGN
+    / bench figures for those kernels at this size are only worth quoting if the frames they produce are the reference's:
+    every pose and the whole model against the oracle's display() loop (D1/GP-demo.cpp:138-296), bit for bit."""
+    n, m = 1080, 1920
+    calib = synth.calib_for(n, m)
+    pool = synth.sequence(4, n, m, calib, noise_sigma=0.001)
+    dd = [torch.from_numpy(p[0]).cuda() for p in pool]
+    bb = [torch.from_numpy(p[1]).cuda() for p in pool]
+    eq, centers = synth.plane_equations()
+    order = [1, 2, 3, 2, 1, 0, 1, 2]
+    rg = pkg.RG(n, m, calib)
+    rg.set_icp_loop(icp_loop)
+    rg.run_device_sequence(dd[:1], bb[:1])
+    rg.set_planes(eq, centers)
+    tracked = rg.run_device_sequence([dd[i] for i in order], [bb[i] for i in order])
+    hist = rg.history(0, 1 + len(order))
+
+    orc.use_openmp(True)
+    try:
+        ref = orc.Slam(n, m, calib)
+        ref.step(*pool[0])
+        ref.set_planes(eq, centers)
+        want = 0
+        for f, i in enumerate(order, start=1):
+            st = ref.step(*pool[i])
+            want += 1 if st else 0
+            R, t = ref.pose()
+            assert int(hist[f, 12]) == (1 if st else 0), "frame %d status" % f
+            same(hist[f, :9], R, "frame %d poseR" % f)
+            same(hist[f, 9:12], t, "frame %d poset" % f)
+        assert tracked == want == len(order)
+        nb = compare_model(rg, ref, "1080p after %d frames" % len(order))
+        assert nb == 3
+        assert sum(int((ref.buffer("Maskb%d" % p) > 10).sum()) for p in range(nb)) > 100000, "the planes were fused into"
+        ref.close()
+    finally:
+        orc.use_openmp(False)
+    if icp_loop:
+        assert rg.icp_loop_faults() == 0
+    rg.close()
+
+
+@pytest.mark.parametrize("icp_loop", [True, False])
 def test_finish_cycle_inside_a_recorded_sequence(pkg, orc, synth, tmp_path, icp_loop):
     """`--finish-period 100` inside run_device_sequence: RG::Finish's first detection (frame 29) and its periodic dump +
     plane reset + re-detection (frame 98; RG.cpp:187-270) land in the MIDDLE of one recorded sequence, where the previous
