@@ -386,7 +386,7 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     float (&solve_sh)[2] = S.solve_sh;
     IcpState &sst = S.sst;
     float (&spose)[24] = S.spose;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = LOOP ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63;   // scalar in the loop: see want_next
     const int nblk = a.rows_local * a.grid_cols;
     const int nwg = min(a.nchain, ICP_WGS);             // workgroups of this launch / step
     const int half = wave / ICP_CHAIN_WAVES, wv = wave - half * ICP_CHAIN_WAVES;   // chain of this wave: t + 256 * half
@@ -448,8 +448,14 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     };
     bool want_next = false;                           // this step requests the next level's samples (after its own gather)
     if (LOOP) {
-        if (mc.lvl != a.lvl) {                        // first step of a level
-            if (mc.nlvl == a.lvl) {                   // its samples were requested a level ago
+        // The level tags are the same in every lane, but live in vector registers: read back as scalars, so that `want_next`
+        // is uniform to the compiler and the branch round request_next below is a SCALAR branch.  As a lane-mask branch its
+        // if / else had a third path in the control-flow graph (both bodies skipped by their execz jumps) on which the
+        // gather was still pending, so the wait counts behind the join were those of a wave WITHOUT the six requests --
+        // vmcnt(3) .. vmcnt(0) -- and the first step of a level waited for the next level's samples after all.
+        const int have_lvl = __builtin_amdgcn_readfirstlane(mc.lvl), have_next = __builtin_amdgcn_readfirstlane(mc.nlvl);
+        if (have_lvl != a.lvl) {                      // first step of a level
+            if (have_next == a.lvl) {                 // its samples were requested a level ago
                 mc.r0 = icp_model_from_raw(mc.n0); mc.r1 = icp_model_from_raw(mc.n1);
                 mc.in0 = mc.nin0; mc.in1 = mc.nin1;
             } else {                                  // first level of the frame: both rounds' pixels are requested at once
@@ -528,10 +534,16 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             IcpRow q;
 #pragma unroll
             for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
+#ifndef ICP_REQUEST_IN_ROUND
+            if (LOOP && r == 0 && want_next && t == nwg - 1) request_next();   // the tail: see below
+#endif
             IcpProj pr = icp_project(mp, Rc, tc3, in4, a.n, a.m);
             IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
+#ifdef ICP_REQUEST_IN_ROUND
             if (LOOP && r == 0 && want_next) { request_next(); icp_pin_gather_after_prefetch(cu); }
-            else icp_pin_gather(cu);
+            else
+#endif
+            icp_pin_gather(cu);
             int proj = -1;
             const bool ok = icp_rows(mp, pr, cu, in4, a.distThres, a.angleThres, inside, q, proj);
             if (!LOOP && a.corr && inside) a.corr[idx] = ok ? proj : -1;
@@ -558,7 +570,12 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             }
             float sum = fold27(v, lane, tr[wave]);
             if (lane < 27) part[r & 1][wave][lane] = sum;
-        } else if (LOOP && r == 0 && want_next) request_next();   // a wave without a block at this level may have one at the next
+        }
+#ifdef ICP_REQUEST_IN_ROUND
+        else if (LOOP && r == 0 && want_next) request_next();   // a wave without a block at this level may have one at the next
+#else
+        else if (LOOP && r == 0 && want_next && t == nwg - 1) request_next();
+#endif
         // ONE barrier per round: the block sums alternate between two sets, and the two accumulating waves pass the next
         // round's barrier only after they have read this round's set -- nobody can overwrite it before (round r + 2)
         __syncthreads();
@@ -588,6 +605,15 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         if (lane < 32)
             __hip_atomic_store((unsigned int *)a.chains + 32 * icp_chain_line(t) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifndef ICP_REQUEST_IN_ROUND
+    // The next level's samples are requested HERE, behind the step's last use of a loaded value, not inside the match round:
+    // there the branch round the six loads joined paths with different numbers of requests in flight, and the wait counts
+    // the compiler places behind such a join are those of the path with the fewest -- the first step of a level waited for
+    // the next level's samples (12 MB of cold model maps at level 1) in the middle of its match phase.  The tail is the
+    // exception: it is about to poll the lines, and loads return in order, so it has made its requests BEFORE its gather
+    // (above) -- half a microsecond ahead of everybody else's step, which the hand-over it does not need pays for.
+    if (LOOP && want_next && t != nwg - 1) request_next();
+#endif
     long long ts2 = a.timing ? wall_clock64() : 0;
     // No arrival counter: the LAST workgroup of the step (it is dispatched last and owns the shortest chains) is the tail.
     // It re-reads the published lines until every one carries this step's sequence words -- one round trip after the
