@@ -380,7 +380,8 @@ template <bool LOOP, bool XCHG>
 __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpShared &S, IcpLoopCtl lc, const int tid, const int t,
                                               IcpModelCache &mc) {
     float (&part)[2][ICP_MAX_WAVES][27] = S.part;
-    float (&accB)[27] = S.accB;
+    float (&accB)[27] = S.accB;                     // only the -DICP_ACC_TWO_WAVES form (A/B) uses it
+    (void)accB;
     float (&tr)[ICP_MAX_WAVES][27 * 8] = S.tr;
     float (&fin)[27] = S.fin;
     float (&solve_sh)[2] = S.solve_sh;
@@ -471,7 +472,13 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         inside = mc.in0;
         mp = mc.r0;
     } else if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
+#ifdef ICP_LOOP_ALL_BARRIERS
     __syncthreads();
+#else
+    // persistent loop after step 0: nothing above has written to LDS, and the barrier behind the hand-over poll (k_icp_loop)
+    // already stands between the new state in sst and its readers
+    if (!LOOP || a.first_launch) __syncthreads();
+#endif
     if (!LOOP && (sst.fail || (a.iter > 0 && sst.cvg))) {   // converged / failed earlier: the whole grid leaves
         if (a.final_launch && t == 0 && tid == 0) {
             IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
@@ -579,24 +586,42 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         // ONE barrier per round: the block sums alternate between two sets, and the two accumulating waves pass the next
         // round's barrier only after they have read this round's set -- nobody can overwrite it before (round r + 2)
         __syncthreads();
+#ifdef ICP_ACC_TWO_WAVES
         if (wv == 0 && lane < 27) {                   // the first wave of each chain adds its chain's blocks in chain order
             int cnt = min(ICP_CHAIN_WAVES, chain_len - r * ICP_CHAIN_WAVES);
             for (int w = 0; w < cnt; w++) acc += part[r & 1][wave + w][lane];
         }
+#else
+        // wave 0 adds BOTH chains' blocks in chain order, chain t in lanes 0..26 and chain t + 256 in lanes 32..58: the two
+        // sums meet through a lane exchange below instead of an LDS word and one more workgroup barrier per step
+        if (wave == 0 && (lane & 31) < 27) {
+            const int hb = lane >> 5;
+            const int len_h = max(0, (nblk - (t + ICP_WGS * hb) + ICP_CHAINS - 1) / ICP_CHAINS);
+            const int cnt = min(ICP_CHAIN_WAVES, len_h - r * ICP_CHAIN_WAVES);
+            for (int w = 0; w < cnt; w++) acc += part[r & 1][hb * ICP_CHAIN_WAVES + w][lane & 31];
+        }
+#endif
     }
     long long ts1 = a.timing ? wall_clock64() : 0;
     // offset 256 of reduce<512> (ICP.cu:35): chain t + chain t+256, added here instead of in the tail (a chain that does
     // not exist contributes the 0 the reference's memset leaves in its place)
+#ifdef ICP_ACC_TWO_WAVES
     if (wave == ICP_CHAIN_WAVES && lane < 27) accB[lane] = acc;
     __syncthreads();
+#endif
     // Publish the 27 sums to the other XCDs without an L2 write-back and without waiting for an acknowledgement: ONE
     // wave-wide agent-scope (write-through) store puts them into line icp_chain_line(t) of the chain buffer, laid out
     // like the state line of the persistent loop -- term k in slot k + k/7, and a.seq (unique per launch / step) in the
     // last slot of every 32-byte sector.  The reader checks those sequence words (below) instead of anyone waiting.
     if (wave == 0) {
-        const float out = acc + accB[lane < 27 ? lane : 0];
         const int k = lane - (lane >> 3);             // term held by slot `lane`
+#ifdef ICP_ACC_TWO_WAVES
+        const float out = acc + accB[lane < 27 ? lane : 0];
         const float v = __shfl(out, k < 27 ? k : 0);
+#else
+        const int kq = k < 27 ? k : 0;
+        const float v = __shfl(acc, kq) + __shfl(acc, kq + 32);   // chain t + chain t + 256 (a chain that does not exist has added nothing)
+#endif
         unsigned int word = ((lane & 7) == 7) ? a.seq : __float_as_uint(v);
         if (a.line_check) {                               // slot 30: integrity word of the 27 sums
             const unsigned int chk = icp_line_xor_lo(word, lane);
@@ -873,7 +898,12 @@ void k_icp_loop(IcpLoopArgs L) {
             a.frame_index = L.frame_index;
             icp_iter_body<true, XCHG>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps, CHECK}, tid, t, mc);
         }
+#ifdef ICP_LOOP_ALL_BARRIERS
         __syncthreads();                               // every thread is done with S
+#endif
+        // No barrier in front of the poll: wave 0 writes the new state into sst_, whose readers (the pose reads at the top of
+        // the step) all lie in front of the step's round barriers, which wave 0 has passed too; the tail's other LDS traffic
+        // (tree, solve) ends at barriers inside icp_iter_body.
         if (tid < 64) {                                // wave 0 polls the published line, one word per lane
             const long long t0 = wall_clock64();
             int nxt;
