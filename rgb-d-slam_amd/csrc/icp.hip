@@ -1116,6 +1116,11 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
         Arow[k] = sums[i * 7 - (i * (i - 1)) / 2 + (j - i)];     // SYM_A(sums, r, k) for r < 6, b[k] for r == 6
         Lr[k] = 0.0f;
     }
+#ifndef ICP_SOLVE_NO_PIN
+    // all six reads in flight before the first column: left alone, each is sunk to the column that uses it and becomes an
+    // LDS round trip of its own on the serial path
+    asm volatile("" : "+v"(Arow[0]), "+v"(Arow[1]), "+v"(Arow[2]), "+v"(Arow[3]), "+v"(Arow[4]), "+v"(Arow[5]));
+#endif
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         float s = Arow[k], w = Arow[k], Lk[6];
