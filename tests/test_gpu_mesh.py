@@ -96,6 +96,43 @@ def test_bump_mesh_fused_equals_three_passes(ctx, orc, pair, synth, variant, inv
     same(host(g_n), host(outs[3][1]))
 
 
+@pytest.mark.parametrize("n,m,skew", [(40, 200, 0), (48, 256, 0), (48, 256, 1), (33, 132, 1)])
+def test_bump_mesh_wide_and_narrow_paths_mixed(ctx, orc, n, m, skew):
+    """k_bump_mesh takes its inputs and writes its vertices / normals full width where a tile allows it (m % 4 == 0, a full
+    64-cell tile column, 16 full rows for the inputs, aligned planes) and narrow elsewhere: sizes with full AND partial
+    tiles in one launch, and planes that start 4 (outputs) / 1 (inputs) bytes off alignment (skew), against the oracle."""
+    rng = np.random.default_rng(n * 1000 + m + skew)
+    bump = rng.integers(20000, 40000, (n, m, 3)).astype(np.uint16)
+    rgbb = rng.integers(0, 256, (n, m, 3)).astype(np.uint8)
+    mask = rng.choice(np.array([0, 1, 10, 11, 12, 30, 255], np.uint8), (n, m))
+    param = np.array([0.0, 0.0, 1.0, 1.2, 500.0, 500.0, -0.1, -0.2, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0], np.float32)
+
+    def dev_skewed(a):                                   # the same data, 2 * skew bytes (u16) / skew bytes (u8) into a larger buffer
+        flat = torch.zeros(a.size + 8, dtype=torch.from_numpy(a).dtype, device="cuda")
+        flat[skew:skew + a.size] = torch.from_numpy(a).reshape(-1).cuda()
+        return flat[skew:skew + a.size].view(*a.shape)
+
+    def out_skewed(ch):
+        flat = torch.empty(n * m * ch + 8, device="cuda")
+        return flat[skew:skew + n * m * ch].view(n, m, ch)
+
+    g = [dev_skewed(bump), dev_skewed(rgbb), dev_skewed(mask), dev(param)]
+    outs = [[out_skewed(ch)] for ch in (3, 4, 4, 3)]
+    if skew:
+        assert outs[0][0].data_ptr() % 16 == 4 and g[1].data_ptr() % 4 == 1
+    idx = [torch.empty((n - 1) * (m - 1), 4, dtype=torch.int32, device="cuda")]
+    # RGBA / MaskOut / Index are written as 16-byte words by every path: those planes stay aligned
+    outs[1] = [torch.empty(n, m, 4, device="cuda")]
+    outs[2] = [torch.empty(n, m, 4, device="cuda")]
+    ctx.bump_mesh_batch(*[_ptr_table(x) for x in outs], _ptr_table(idx), *[_ptr_table([x]) for x in g], 0, 1, n, m, 1, 0.01, True, 0)
+    rv, rc, rk = orc.vertex_from_bump(bump, rgbb, mask, param, 1)
+    same(host(outs[0][0]), rv)
+    same(host(outs[1][0]), rc)
+    same(host(outs[2][0]), rk)
+    same(host(outs[3][0]), orc.compute_normal(rv, True))
+    same(host(idx[0]).view(np.uint32), orc.quad_trim(rv, mask, 1, 0.01, 1, 0))
+
+
 def test_bump_mesh_odd_size_and_errors(ctx, orc, pkg):
     n, m = 37, 101
     rng = np.random.default_rng(1)
