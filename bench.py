@@ -450,10 +450,11 @@ def run_planes(args, env):
         tracked = 0
         if rank == 0:
             rg.synchronize()
-            h = rg.history(rg.frames_done() - args.steps, args.steps)
+            hn = min(args.steps, pkg.RG.HISTORY_CAP)             # (a longer run: the frames the history ring still holds)
+            h = rg.history(rg.frames_done() - hn, hn)
             tracked = int((h[:, 12] == 1.0).sum())
-            if tracked != args.steps:
-                raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
+            if tracked != hn:
+                raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (hn - tracked, hn))
             if loop_ok and rg.icp_loop_faults():
                 raise SystemExit("the persistent ICP kernel gave up waiting for its grid: result invalid")
         # ---- second pass (untimed): phases by events on rank 0's streams, decode kernel by the library's event hook ----
@@ -841,10 +842,11 @@ def main():
     # iteration counts of EVERY profiled frame (history ring: 16 floats per frame, [14] = executed iterations per level,
     # 8 bits each), not just the last one's
     fd = rg.frames_done()
-    hist = rg.history(fd - args.steps, args.steps)
+    hn = min(args.steps, pkg.RG.HISTORY_CAP)                 # a longer run (soak): the frames the ring still holds
+    hist = rg.history(fd - hn, hn)
     packed = hist[:, 14].astype(np.int64)
     per_level_total = [int(((packed >> (8 * k)) & 255).sum()) for k in range(3)]
-    level_iters = [round(t / float(args.steps), 2) for t in per_level_total]
+    level_iters = [round(t / float(hn), 2) for t in per_level_total]
     tot_ms, launches = C.c_double(), C.c_int()
     lib.rgbdslam_profile_read(ctx, C.byref(tot_ms), C.byref(launches))
     lib.rgbdslam_profile_kernel(ctx, None)
@@ -862,7 +864,7 @@ def main():
                            "so its own span is the two event records only")
     per_frame_launches = launches.value / float(args.steps)
     if args.kernel in ("k_icp_iter", "k_icp_loop"):
-        bytes_all_frames = algo_bytes(args.kernel, n, m, per_level_total)
+        bytes_all_frames = algo_bytes(args.kernel, n, m, [t * (args.steps / float(hn)) for t in per_level_total])   # (hn < steps: the mean of the frames still in the ring)
     else:
         bytes_all_frames = PER_PX[args.kernel] * n * m * launches.value
     bytes_per_frame = bytes_all_frames / float(args.steps)

@@ -474,6 +474,8 @@ class RG:
         under `rocprofv3 --pmc`, which would hang the value waits).  Before the first frame."""
         _hchk(self.lib.slamhost_rg_set_stream_events(self._h, int(on)), "set_stream_events")
 
+    HISTORY_CAP = 8192        # frames the pose history ring holds (slam::RG::HISTORY_CAP, host/rgbdslam_host.hpp)
+
     def history(self, first, count):
         """Poses of frames [first, first+count): rows of poseR(9, col-major) poset(3) tracked iterations level_iters 0."""
         import numpy as np
