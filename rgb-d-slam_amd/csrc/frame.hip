@@ -84,7 +84,7 @@ __device__ __forceinline__ PdVert pd_vertex(const float *P, const CalibV &c, F3 
     if (!exists) { o.v.x = o.v.y = o.v.z = 0.0f; o.p.X = 0; o.p.Y = 0; o.p.inv_d = 0.0; o.p.ok = false; }
     return o;
 }
-__global__ __launch_bounds__(TILE_W * TILE_H)
+__global__ __launch_bounds__(TILE_W * TILE_H)      // (70 registers = 7 waves per SIMD; held to 64 for 8 it spills four and gains nothing)
 void k_predict_draw(const rgbdslam_pose_block *__restrict__ pb, const float *__restrict__ VMap,
                     unsigned long long *__restrict__ zbuf, float thresh, CalibV c, float znear, float zfar,
                     UpdateArgs upd, int rows_draw, ProjVert *__restrict__ pv, float *__restrict__ zw, int n, int m) {
@@ -630,8 +630,16 @@ __device__ __forceinline__ void segment3_claim_tile(const SegArgsT<LT> &sg, cons
 // tile rows of the image; rows from there on (if the grid has them) preprocess the NEXT input frame (OffLineFrame::LoadFrame
 // of frame f+1 into buffers nothing in this launch reads): the job is independent of everything here and its ~11 us of
 // dependent steps fit under this launch's own.
+// 65 registers would leave 7 waves per SIMD; held to 64 the kernel runs 8 (a handful of scalar spills to lanes, no vector
+// ones): 119.0 -> 108.7 us at 1920x1080, 26.0 -> 25.8 us at 640x480 (same-box, tools/ab_large.sh)
+#ifndef SEG3_WAVES_PER_EU
+#define SEG3_WAVES_PER_EU 8
+#endif
 template <typename LT>
 __global__ __launch_bounds__(TILE_W * TILE_H)
+#if SEG3_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(SEG3_WAVES_PER_EU)))
+#endif
 void k_segment3_merge_claim(SegArgsT<LT> sg, MergeArgs mg, PreprocessArgs pp, int rows2) {
     if ((int)blockIdx.y >= rows2) {
         frame_preprocess_tile(pp, blockIdx.x, (int)blockIdx.y - rows2);
