@@ -65,7 +65,6 @@ void k_bump_mesh(float *const *__restrict__ VMapTab, float *const *__restrict__ 
     __shared__ __align__(16) float sv[MHALO_H][MESH_SV_STRIDE];
     __shared__ uint8_t sm[MHALO_H][HALO_W];
     __shared__ float lut[256];                                   // x / 255 for every byte: one division per thread
-    __shared__ __align__(16) float sn[TILE_H][3 * TILE_W];      // per wave: one row segment of normals as it lies in memory
     const int tid = threadIdx.y * TILE_W + threadIdx.x;
     lut[tid] = unorm8((uint8_t)tid);
     const int plane = plane_lo + blockIdx.z;
@@ -88,6 +87,10 @@ void k_bump_mesh(float *const *__restrict__ VMapTab, float *const *__restrict__ 
     // into LDS instead -- 16 x (384 + 192 + 64) bytes -- and the own cells' bytes are picked from there (k_vertex_from_bump_batch
     // does the same); only the 164 cells of the halo ring are read narrow.
     __shared__ __align__(16) unsigned char stage[MESH_ROWS * 10 * TILE_W];
+    // per wave, one row segment of normals as it lies in memory: in the staging area, which is dead once the tile is decoded
+    // (behind the second barrier) -- 26.9 KB of LDS per workgroup instead of 29.9 KB, i.e. six workgroups per CU instead of five
+    float (*sn)[3 * TILE_W] = (float (*)[3 * TILE_W])stage;
+    static_assert(sizeof(float) * TILE_H * 3 * TILE_W <= MESH_ROWS * 10 * TILE_W, "normals fit in the staging area");
     const bool wide_in = seg && i0 + MESH_ROWS <= n &&
                          (((uintptr_t)Bump & 7) | ((uintptr_t)RGBb & 3) | ((uintptr_t)Maskb & 3)) == 0;
     typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
