@@ -1033,6 +1033,7 @@ __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
         a[k] = v;
     }
     float det = 1.0f;
+    bool done = false;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         int p = c;
@@ -1050,10 +1051,17 @@ __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
             rowp[k] = vp;
             a[k] = (lane == c) ? vp : ((lane == p) ? vc : a[k]);   // exchange rows c and p (no-op when p == c)
         }
-        if (p != c) det = -det;
         float piv = rowp[c];
+#ifdef ICP_SOLVE_EARLY_EXIT
+        if (p != c) det = -det;
         det = det * piv;
         if (piv == 0.0f || piv != piv) return det;
+#else
+        // (no exit inside the elimination either: the value the serial algorithm returns at a zero / NaN pivot is frozen)
+        const float dn = (p != c ? -det : det) * piv;
+        det = done ? det : dn;
+        done |= (piv == 0.0f || piv != piv);
+#endif
         if (lane > c && lane < 6) {
             float f = a[c] / piv;
 #pragma unroll
@@ -1110,6 +1118,7 @@ __device__ __forceinline__ int llt_solve6_reg(const float *sums, float *x) {
 __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, float *x) {
     const int r = lane < 6 ? lane : 6;
     float Arow[6], Lr[6];
+    bool fail = false;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int i = r < k ? r : k, j = r < k ? k : r;
@@ -1131,7 +1140,14 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
             w = w - Lr[p] * Lk[p];                               // meaningful in lanes r > k (lane 6: the forward substitution)
         }
         const float sk = lane_read(s, k);
+#ifdef ICP_SOLVE_EARLY_EXIT
         if (!(sk > 0.0f)) return 1;
+#else
+        // no exit inside the factorisation: a non-positive pivot is remembered and the arithmetic goes on (on values nobody
+        // will use) -- six early exits cut the unrolled code into seven basic blocks, and the scheduler could not move a
+        // column's products with the columns before the last one into the shadow of that one's square root and division
+        fail |= !(sk > 0.0f);
+#endif
         const float lkk = __builtin_sqrtf(sk);
         Lr[k] = (r == k) ? lkk : w / lkk;
     }
@@ -1150,7 +1166,7 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
         for (int p = q + 1; p < 6; p++) u = u - L[p][q] * x[p];
         x[q] = u / L[q][q];
     }
-    return 0;
+    return fail ? 1 : 0;
 }
 
 // pose_state = poseR(9) poset(3) poseRPrev(9) posetPrev(3)
@@ -1236,7 +1252,10 @@ __device__ __forceinline__ float icp_pose_update_wave(const IcpState *st, const 
     // iteration of level 0 the pair is left untouched: the track-loss test reads the LAST
     // uploaded pair, not the final estimate (RG.cpp:910).
     float cv = old_word;
-    if (!cvg || lvl > 0) {
+#ifdef ICP_SOLVE_EARLY_EXIT
+    if (!cvg || lvl > 0)
+#endif
+    {
         float nR[9], nt[3];
 #pragma unroll
         for (int z = 0; z < 9; z++) nR[z] = lane_read(nv, icp_slot_of_word(z));          // the new Rinv
@@ -1245,8 +1264,13 @@ __device__ __forceinline__ float icp_pose_update_wave(const IcpState *st, const 
         const float r0 = i == 0 ? nR[0] : (i == 1 ? nR[1] : nR[2]);                      // its row i
         const float r1 = i == 0 ? nR[3] : (i == 1 ? nR[4] : nR[5]);
         const float r2 = i == 0 ? nR[6] : (i == 1 ? nR[7] : nR[8]);
-        cv = (r0 * p0 + r1 * p1) + r2 * p2;                                              // RG.cpp:851 | 852
-        if (is_t) cv = cv + (i == 0 ? nt[0] : (i == 1 ? nt[1] : nt[2]));
+        float cn = (r0 * p0 + r1 * p1) + r2 * p2;                                        // RG.cpp:851 | 852
+        if (is_t) cn = cn + (i == 0 ? nt[0] : (i == 1 ? nt[1] : nt[2]));
+#ifdef ICP_SOLVE_EARLY_EXIT
+        cv = cn;
+#else
+        cv = (!cvg || lvl > 0) ? cn : old_word;                                          // (a select, not a branch round twelve lane reads)
+#endif
     }
     return role_b ? cv : nv;
 }
@@ -1271,7 +1295,14 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         word = ((const float *)st)[kr];
         iters = st->iters; lvl_iters = st->lvl_iters; cvg = st->cvg;
         llt_fail = wave_llt_solve6(sums, lane, x);             // RG.cpp:873 (wave-uniform result)
+#ifdef ICP_SOLVE_EARLY_EXIT
         if (!llt_fail) new_word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, new_cvg);
+#else
+        // unconditional (a failed factorisation's update is computed on garbage and dropped below): no branch between the
+        // solve and the update, so the quaternion's f64 chain -- it only needs x[3..5], the FIRST results of the backward
+        // substitution -- is scheduled beside the rest of the substitution
+        new_word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, new_cvg);
+#endif
     }
     __syncthreads();
     if (wave != 0) return;
