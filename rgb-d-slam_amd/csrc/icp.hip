@@ -1025,6 +1025,7 @@ __device__ __forceinline__ float lane_read(float v, int src) {
 // pivot are never looked at again and are not exchanged).
 __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
     float a[6];
+#ifdef ICP_DET_NO_PIN
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         float v = 0.0f;
@@ -1032,6 +1033,24 @@ __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
         for (int r = 0; r < 6; r++) v = (lane == r) ? SYM_A(sums, r, k) : v;
         a[k] = v;
     }
+#else
+    // the 21 matrix entries in ONE LDS round trip (left alone the reads are issued and waited for in five or six batches,
+    // each next to its first use), then the rows are picked by lane
+    float sv[21];
+#pragma unroll
+    for (int z = 0; z < 21; z++) sv[z] = sums[z < 6 ? z : z + (z >= 11) + (z >= 15) + (z >= 18) + (z >= 20) + 1];   // tri_idx(i, j) for j < 6: skips the b entries
+    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]), "+v"(sv[8]),
+                 "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[12]), "+v"(sv[13]), "+v"(sv[14]), "+v"(sv[15]), "+v"(sv[16]), "+v"(sv[17]),
+                 "+v"(sv[18]), "+v"(sv[19]), "+v"(sv[20]));
+    auto at = [&](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return sv[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)]; };
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 6; r++) v = (lane == r) ? at(r, k) : v;
+        a[k] = v;
+    }
+#endif
     float det = 1.0f;
     bool done = false;
 #pragma unroll
