@@ -598,7 +598,17 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             const int hb = lane >> 5;
             const int len_h = max(0, (nblk - (t + ICP_WGS * hb) + ICP_CHAINS - 1) / ICP_CHAINS);
             const int cnt = min(ICP_CHAIN_WAVES, len_h - r * ICP_CHAIN_WAVES);
+#ifdef ICP_ACC_LOOP
             for (int w = 0; w < cnt; w++) acc += part[r & 1][hb * ICP_CHAIN_WAVES + w][lane & 31];
+#else
+            // all six slots are read at once (one LDS round trip instead of one per block, in a loop whose trip count differs
+            // between the lanes) and added in chain order under selects; a slot beyond the chain's end holds an older round's sum
+            float pv[ICP_CHAIN_WAVES];
+#pragma unroll
+            for (int w = 0; w < ICP_CHAIN_WAVES; w++) pv[w] = part[r & 1][hb * ICP_CHAIN_WAVES + w][lane & 31];
+#pragma unroll
+            for (int w = 0; w < ICP_CHAIN_WAVES; w++) { const float nx = acc + pv[w]; acc = w < cnt ? nx : acc; }
+#endif
         }
 #endif
     }
