@@ -557,6 +557,112 @@ def test_icp_row_bands_and_gathered_solve(ctx, pkg, orc, pair):
     assert np.abs(s[:9] - R).max() <= 1e-5 and np.abs(s[9:12] - t).max() <= 1e-5
 
 
+def _pack27(A, b):
+    """(A symmetric 6x6, b) -> the 27 sums as the reduction leaves them: row i = A[i][i..5], b[i] (ICP.cu:178-191)."""
+    s = []
+    for i in range(6):
+        s.extend(A[i, i:])
+        s.append(b[i])
+    return np.asarray(s, np.float32)
+
+
+def _solve_cases():
+    rng = np.random.default_rng(77)
+    cases = []
+    for k in range(24):                                           # well-posed: J^T J of a random Jacobian
+        J = rng.standard_normal((40 + k, 6)).astype(np.float32) * np.float32(10.0 ** rng.integers(-1, 3))
+        A = (J.T @ J).astype(np.float32)
+        A = np.triu(A) + np.triu(A, 1).T                          # exactly symmetric
+        xs = (rng.standard_normal(6) * 1e-2).astype(np.float32)
+        cases.append(("spd%d" % k, A, (A @ xs).astype(np.float32)))
+    b = (rng.standard_normal(6) * 1e-3).astype(np.float32)
+    d = lambda *v: np.diag(np.asarray(v, np.float32))
+    cases.append(("zero", np.zeros((6, 6), np.float32), b))
+    cases.append(("first pivot negative, det +1", d(-1, -1, 1, 1, 1, 1), b))
+    cases.append(("last pivot negative", d(1, 1, 1, 1, 1, -1), b))
+    cases.append(("middle pivot zero", d(1, 1, 0, 1, 1, 1), b))
+    cases.append(("positive definite, |det| < 1e-15", d(*[1e-3] * 6), b * np.float32(1e-3)))
+    cases.append(("positive definite, det just above", d(*[4e-3] * 6), b * np.float32(1e-3)))
+    A = d(2, 2, 2, 2, 2, 2); A[2, 3] = A[3, 2] = np.nan
+    cases.append(("nan off the diagonal", A, b))
+    A = d(2, 2, 2, 2, 2, 2); A[4, 4] = np.nan
+    cases.append(("nan on the diagonal", A, b))
+    A = d(2, 2, 2, 2, 2, 2); A[0, 0] = np.inf
+    cases.append(("inf pivot", A, b))
+    A = d(1, 1, 1, 1, 1, 1); A[0, 1] = A[1, 0] = 2.0                # indefinite through an off-diagonal, det = -3
+    cases.append(("indefinite off-diagonal", A, b))
+    J = rng.standard_normal((5, 6)).astype(np.float32)              # rank 5: the last pivot is rounding noise of either sign
+    A = (J.T @ J).astype(np.float32); A = np.triu(A) + np.triu(A, 1).T
+    cases.append(("rank deficient", A, b))
+    cases.append(("nan right-hand side", d(2, 2, 2, 2, 2, 2), np.asarray([0, 0, np.nan, 0, 0, 0], np.float32)))
+    return cases
+
+
+def test_icp_solve_step_on_crafted_systems(ctx, pkg, orc, pair):
+    """ONE solve step (k_icp_solve: wave_llt_solve6 + wave_det6 + the pose update, the code k_icp_loop's tail runs) on
+    crafted 6x6 systems, against the oracle's orc_llt_solve6 / orc_det6 and the lost-frame rule of RG.cpp:862-873:
+    the increment x bit-exact where the step is accepted; where it is not -- non-positive pivot at any position, NaN /
+    Inf entries, |det| < 1e-15 although the factorisation succeeds -- no iteration is counted, the frame is reported
+    lost and the caller's pose is untouched.  Pins the branch-free forms of the solve, the determinant and the update
+    (a failed factorisation's update runs on garbage and must be dropped)."""
+    import ctypes as C
+    ctx.set_calibration_matrix(pair["calib"])
+    ctx.alloc_buffers(60, 80)
+    prm = pkg.icp_params()
+    lib = ctx.lib
+    p = lambda t: C.c_void_p(t.data_ptr())
+    I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+    pose0 = np.concatenate([I, z, I, z]).astype(np.float32)
+    accepted = rejected = 0
+    for name, A, b in _solve_cases():
+        rc_ref, x_ref = orc.llt_solve6(A, b)
+        det = np.float32(orc.det6(A))
+        lost = bool(rc_ref != 0 or np.isnan(det) or float(abs(det)) < 1e-15)
+        state = dev(pose0); status = torch.full((4,), -7, dtype=torch.int32, device="cuda")
+        sums = dev(_pack27(A, b)); trace = torch.full((2, 33), -1.0, device="cuda")
+        assert lib.rgbdslam_align_begin(ctx._h, p(state), p(status)) == 0
+        assert lib.rgbdslam_align_solve_gathered(ctx._h, C.byref(prm), p(sums), 1, p(state), 2, 0, p(trace)) == 0
+        assert lib.rgbdslam_align_end(ctx._h, p(state), p(status)) == 0
+        ctx.synchronize()
+        st, tr, s = host(status), host(trace), host(state)
+        if lost:
+            rejected += 1
+            assert st[0] == 0 and st[1] == 0 and st[2] == 0, (name, st)
+            same(s, pose0)                                           # the pose the caller holds is untouched
+            assert (tr == -1.0).all(), name                          # and nothing was traced
+        else:
+            accepted += 1
+            assert st[1] == 1 and st[2] == 1 << 16, (name, st)
+            same(tr[0, :27], _pack27(A, b))
+            same(tr[0, 27:], x_ref)                                  # bit-exact increment
+            if not np.isnan(x_ref).any():                            # (a NaN right-hand side passes RG.cpp:862-873 and, NaN
+                                                                     # comparing false, RG.cpp:910 too: only x is checked)
+                assert st[0] == 1, (name, st)
+                # identity start: tinv = x[0..2] and Rinv = Rinc exactly, so the pose is inverse(Rinc), -inverse(Rinc) x[0..2]
+                q = np.asarray([0.0, x_ref[3], x_ref[4], x_ref[5]], np.float64)
+                q[0] = np.sqrt(1.0 - float(np.float32(np.float32(x_ref[3] * x_ref[3] + x_ref[4] * x_ref[4]) + x_ref[5] * x_ref[5])))
+                Rinc = np.asarray([[q[0]**2 + q[1]**2 - q[2]**2 - q[3]**2, 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2])],
+                                   [2 * (q[1] * q[2] + q[0] * q[3]), q[0]**2 - q[1]**2 + q[2]**2 - q[3]**2, 2 * (q[2] * q[3] - q[0] * q[1])],
+                                   [2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), q[0]**2 - q[1]**2 - q[2]**2 + q[3]**2]])
+                R = np.linalg.inv(Rinc)
+                assert np.abs(s[:9].reshape(3, 3).T - R).max() <= 1e-5, name
+                assert np.abs(s[9:12] + R @ x_ref[:3].astype(np.float64)).max() <= 1e-5, name
+    assert accepted >= 24 and rejected >= 9, (accepted, rejected)
+
+    # a failed step after an accepted one: the count stays at one, the frame is lost, the pose untouched
+    name, A, b = _solve_cases()[0]
+    state = dev(pose0); status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    good = dev(_pack27(A, b)); bad = dev(_pack27(-A, b))
+    assert lib.rgbdslam_align_begin(ctx._h, p(state), p(status)) == 0
+    assert lib.rgbdslam_align_solve_gathered(ctx._h, C.byref(prm), p(good), 1, p(state), 2, 0, None) == 0
+    assert lib.rgbdslam_align_solve_gathered(ctx._h, C.byref(prm), p(bad), 1, p(state), 2, 1, None) == 0
+    assert lib.rgbdslam_align_end(ctx._h, p(state), p(status)) == 0
+    ctx.synchronize()
+    st = host(status)
+    assert st[0] == 0 and st[1] == 1, st
+    same(host(state), pose0)
+
+
 def test_update_plane_partition(ctx, orc, pair, synth):
     """Plane-partitioned fusion: shards [0,1) and [1,3) together equal the unpartitioned result."""
     n, m = 480, 640
