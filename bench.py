@@ -855,7 +855,11 @@ def main():
         raise SystemExit("tracking lost on %d of %d timed frames: result invalid" % (args.steps - tracked, args.steps))
     # poses of the warm-up and the timed frames as the device left them (compared with the oracle's in the cpu_baseline leg)
     gpu_first = SETUP
-    gpu_hist = rg.history(gpu_first, min(args.warmup + args.steps, max(0, 3 * args.cpu_frames))) if rank == 0 and world == 1 and args.cpu_frames > 0 else None
+    # a soak longer than the history ring has overwritten the frames the oracle leg can reach: the line then says so instead of
+    # carrying a comparison (the default run and every run up to HISTORY_CAP frames carry it)
+    ring_wrapped = SETUP + args.warmup + args.steps > pkg.RG.HISTORY_CAP
+    gpu_hist = (rg.history(gpu_first, min(args.warmup + args.steps, max(0, 3 * args.cpu_frames)))
+                if rank == 0 and world == 1 and args.cpu_frames > 0 and not ring_wrapped else None)
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches ----
     level_iters = [0, 0, 0]
@@ -1026,7 +1030,9 @@ def main():
                   "max_abs_pose_diff": checked["max_abs"], "tolerance": 1e-5,
                   "what": "pose history (poseR, poset, tracked flag) of the warm-up + timed frames on the GPU vs the oracle's display() loop "
                           "over the same frames, in this run"}
-        if checked["bad"] or checked["frames"] == 0:
+        if ring_wrapped:
+            parity = None
+        elif checked["bad"] or checked["frames"] == 0:
             print(json.dumps({"parity_in_run": parity, "first_bad_frames": checked["bad"][:8]}), file=sys.stderr, flush=True)
             raise SystemExit("parity_in_run failed: the GPU pose history differs from the oracle's on %d of %d frames: result invalid"
                              % (len(checked["bad"]), checked["frames"]))
@@ -1049,7 +1055,9 @@ def main():
                           "icp": "one persistent launch per frame (k_icp_loop)" if args.icp_loop else "12 k_icp_iter launches per frame",
                           "finish_period": args.finish_period,
                           "preheat_ms": args.preheat_ms},        # untimed load in front of the warm-up (see --preheat-ms)
-               "parity_in_run": parity, "stage_times": stage_times, "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
+               "parity_in_run": parity,
+               "parity_in_run_skipped": ("%d frames overwrite the %d-frame pose history ring before it can be read" % (SETUP + args.warmup + args.steps, pkg.RG.HISTORY_CAP)) if ring_wrapped else None,
+               "stage_times": stage_times, "value_with_h2d": value_with_h2d, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "hbm_bound_kernels": large, "hbm_stream_probe": probe}
         print(json.dumps(check_line(out)), flush=True)
     rg.close()
     if world > 1:
