@@ -42,6 +42,16 @@ int rgbdslam_destroy(rgbdslam_ctx *ctx);
 int rgbdslam_set_stream(rgbdslam_ctx *ctx, void *stream);
 int rgbdslam_get_stream(rgbdslam_ctx *ctx, void **stream);
 int rgbdslam_synchronize(rgbdslam_ctx *ctx);
+/* rgbdslam_synchronize() polls the stream for up to `microseconds` before it blocks (default 5000, or RGBDSLAM_SYNC_SPIN_US
+ * at create; 0 = block at once).  A blocked wait is woken tens of microseconds after the stream drains; the frame is 112 us.
+ * No reference counterpart (the reference blocks in cudaDeviceSynchronize after every wrapper). */
+int rgbdslam_set_sync_spin(rgbdslam_ctx *ctx, int microseconds);
+/* Stores up to RGBDSLAM_COPY_MAX_SEGMENTS device ranges into memory the device can write -- pinned host memory, or device
+ * memory -- with ONE launch on the context's stream (no reference counterpart: the reference reads its poses back with blocking
+ * cudaMemcpy, RG.cpp:898-903; a hipMemcpyAsync per range is a blit launch each).  Addresses and sizes are multiples of 4
+ * bytes; asynchronous, the data is on the host after rgbdslam_synchronize(). */
+#define RGBDSLAM_COPY_MAX_SEGMENTS 4
+int rgbdslam_copy_segments(rgbdslam_ctx *ctx, const void *const *src_dev, void *const *dst, const size_t *bytes, int count);
 const char *rgbdslam_version(void);
 /* Instrumentation (no reference counterpart; the reference's only timing is clock() prints behind
  * `#define TIMING`, Utilities.h:82): brackets every later launch of the kernel called `kernel_name`

@@ -45,6 +45,7 @@ struct rgbdslam_ctx {
     int icp_loop;                  // rgbdslam_set_icp_loop
     int icp_line_check;            // rgbdslam_set_icp_line_check
     int icp_timeout_ticks;         // rgbdslam_debug_set_icp_timeout
+    int sync_spin_us;              // rgbdslam_synchronize polls the stream this long before it blocks (rgbdslam_set_sync_spin)
     int seg3_fused;                // rgbdslam_model_segment_merge_claim as one launch (RGBDSLAM_SEG3=0: the three-launch form)
     // instrumentation (rgbdslam_profile_*): HIP-event pairs around every launch of one named kernel
     const char *prof_name;

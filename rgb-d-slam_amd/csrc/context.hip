@@ -2,6 +2,7 @@
 // (calib_dev/pose_dev D1/Kernel.cu:6-7, buf_dev/outbuf_dev/buf D1/ICP.cu:5-7).
 #include "common.hpp"
 #include <new>
+#include <chrono>
 #include <string.h>
 #include <stdlib.h>
 
@@ -21,6 +22,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->buf_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr; c->icp_epoch_dev = nullptr; c->icp_block = nullptr; c->icp_epoch_base = 0; c->icp_loop = 0; c->icp_line_check = 0; c->icp_timeout_ticks = 5000000;
     { const char *e = getenv("RGBDSLAM_SEG3"); c->seg3_fused = !(e && e[0] == '0'); }
+    { const char *e = getenv("RGBDSLAM_SYNC_SPIN_US"); c->sync_spin_us = e ? atoi(e) : 5000; if (c->sync_spin_us < 0) c->sync_spin_us = 0; }
     for (int k = 0; k < RGBDSLAM_COMPAT_MAX_PLANES; k++) c->claim_slab[k] = nullptr;
     c->claim_tab_dev = nullptr; c->claim_cells = 0; c->claim_stamp = 0; c->label_swap = nullptr; c->label_swap_px = 0; c->compat_counter = nullptr;
     for (int k = 0; k < 8; k++) c->xchg_peer[k] = nullptr;
@@ -100,9 +102,70 @@ extern "C" int rgbdslam_get_stream(rgbdslam_ctx *ctx, void **stream) {
     return 0;
 }
 
+// A blocked hipStreamSynchronize is woken by an interrupt, tens of microseconds after the stream has drained -- a quarter of a
+// 112-us frame for a caller that waits once per frame, and ~1 % of a 20-frame sequence.  The wait therefore polls the stream
+// first (hipStreamQuery, ~1 us a call) for at most sync_spin_us (default 5 ms, RGBDSLAM_SYNC_SPIN_US / rgbdslam_set_sync_spin;
+// 0 = block at once) and only then blocks: short waits end within a microsecond or two, long ones do not burn a core.
 extern "C" int rgbdslam_synchronize(rgbdslam_ctx *ctx) {
     if (!ctx) return RGBDSLAM_E_ARG;
+    if (ctx->sync_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) return 0;
+            (void)hipGetLastError();                                   // "not ready" is not an error to leave behind
+            if (e != hipErrorNotReady) return -(int)e;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= ctx->sync_spin_us) break;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int rgbdslam_set_sync_spin(rgbdslam_ctx *ctx, int microseconds) {
+    if (!ctx || microseconds < 0) return RGBDSLAM_E_ARG;
+    ctx->sync_spin_us = microseconds;
+    return 0;
+}
+
+// ---- small results to the host without copy commands (no reference counterpart: the reference reads poses back with
+// blocking cudaMemcpy, RG.cpp:898-903) ----------------------------------------------------------------------------------
+// A hipMemcpyAsync device-to-host on a compute stream is a blit launch of its own with its own completion handling
+// (~7 us each in the frame loop's trace); the pose block and the pose history entries a caller reads after a sequence are a
+// few hundred bytes, so ONE launch stores all of them into pinned host memory directly.
+struct CopySegs { const uint32_t *src[RGBDSLAM_COPY_MAX_SEGMENTS]; uint32_t *dst[RGBDSLAM_COPY_MAX_SEGMENTS]; uint32_t words[RGBDSLAM_COPY_MAX_SEGMENTS]; int n; };
+__global__ void k_copy_segments(CopySegs a) {
+    const uint32_t stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < a.n; k++) {
+        const uint32_t *s = a.src[k];
+        uint32_t *d = a.dst[k];
+        const uint32_t w = a.words[k];
+        if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+            const uint32_t q = w >> 2;
+            for (uint32_t i = first; i < q; i += stride) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+            for (uint32_t i = 4 * q + first; i < w; i += stride) d[i] = s[i];
+        } else {
+            for (uint32_t i = first; i < w; i += stride) d[i] = s[i];
+        }
+    }
+}
+
+extern "C" int rgbdslam_copy_segments(rgbdslam_ctx *ctx, const void *const *src_dev, void *const *dst, const size_t *bytes, int count) {
+    if (!ctx || count < 0 || count > RGBDSLAM_COPY_MAX_SEGMENTS || (count && (!src_dev || !dst || !bytes))) return RGBDSLAM_E_ARG;
+    if (count == 0) return 0;
+    CopySegs a = {};
+    size_t most = 0;
+    for (int k = 0; k < count; k++) {
+        if (!src_dev[k] || !dst[k] || (bytes[k] & 3) || (((uintptr_t)src_dev[k] | (uintptr_t)dst[k]) & 3) || bytes[k] > 0xffffffffull)
+            return RGBDSLAM_E_ARG;
+        a.src[k] = (const uint32_t *)src_dev[k]; a.dst[k] = (uint32_t *)dst[k]; a.words[k] = (uint32_t)(bytes[k] / 4);
+        if (bytes[k] > most) most = bytes[k];
+    }
+    a.n = count;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int blocks = (int)((most / 16 + 255) / 256);
+    KLAUNCH(ctx, k_copy_segments, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(256), a);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -1446,20 +1446,35 @@ void RG::SyncAll() {
     _update_pending = false;
 }
 
+// Sync() only if the host's view is behind the device: frames enqueued since the last Sync, or an apply pass pending
+void RG::SyncIfStale() {
+    static const bool always = getenv("RGBDSLAM_SEQ_LEADING_SYNC") != nullptr;      // A/B switch: the unconditional Sync of before
+    if (always || _history_synced != frames_done || _deferred.valid || _update_pending) Sync();
+}
+
 int RG::Sync() {
     FlushDeferredApply();
+    // the pose block and the new history entries (at most two ring segments) go to their pinned mirrors with ONE launch that
+    // stores them there (rgbdslam_copy_segments) instead of two or three copy commands, each a blit launch of its own;
+    // RGBDSLAM_SYNC_COPY_CMDS=1 restores the copy commands
+    static const bool copy_cmds = getenv("RGBDSLAM_SYNC_COPY_CMDS") != nullptr;
     hipStream_t s = ctx_stream(_ctx);
-    hip_check(hipMemcpyAsync(_pb_host, _pb_dev, sizeof(rgbdslam_pose_block), hipMemcpyDeviceToHost, s), "pose block download");
+    const void *src[3]; void *dst[3]; size_t bytes[3]; int nseg = 0;
+    src[nseg] = _pb_dev; dst[nseg] = _pb_host; bytes[nseg] = sizeof(rgbdslam_pose_block); nseg++;
     int lo = _history_synced, hi = frames_done;
     if (hi - lo > HISTORY_CAP) lo = hi - HISTORY_CAP;
     for (int f = lo; f < hi;) {                                                     // ring segments
         int slot = f % HISTORY_CAP, cnt = hi - f;
         if (slot + cnt > HISTORY_CAP) cnt = HISTORY_CAP - slot;
-        hip_check(hipMemcpyAsync(_history_host + 16 * (size_t)slot, _history_dev.p + 16 * (size_t)slot, 64 * (size_t)cnt,
-                                 hipMemcpyDeviceToHost, s), "history download");
+        src[nseg] = _history_dev.p + 16 * (size_t)slot; dst[nseg] = _history_host + 16 * (size_t)slot; bytes[nseg] = 64 * (size_t)cnt; nseg++;
         f += cnt;
     }
-    hip_check(hipStreamSynchronize(s), "sync");
+    if (copy_cmds) {
+        for (int k = 0; k < nseg; k++) hip_check(hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyDeviceToHost, s), "pose / history download");
+    } else {
+        check(rgbdslam_copy_segments(_ctx, src, dst, bytes, nseg), "copy_segments");
+    }
+    check(rgbdslam_synchronize(_ctx), "sync");                                     // polls first, then blocks (rgbdslam_set_sync_spin)
     if (_update_pending) { hip_check(hipStreamSynchronize(_update_stream), "sync update stream"); _update_pending = false; }
     _history_synced = hi;
     memcpy(_poseR.a, _pb_host->pose_state, 36); memcpy(_poset.v, _pb_host->pose_state + 9, 12);
@@ -1661,7 +1676,10 @@ int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, 
     int ok = 0;
     RG *r = (RG *)rg;
     FACADE_TRY(if (r->fused) {
-        r->Sync();
+        static const bool timing = getenv("RGBDSLAM_SEQ_TIMING") != nullptr;    // host-side phases of the call, to stderr
+        const auto c0 = std::chrono::steady_clock::now();
+        r->SyncIfStale();                                      // tracked_total is current unless frames were enqueued since the last Sync
+        const auto c1 = std::chrono::steady_clock::now();
         long before = r->tracked_total;
         for (int k = 0; k < count; k++) {
             r->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
@@ -1670,8 +1688,16 @@ int slamhost_rg_run_device_sequence(void *rg, const uint16_t *const *depth_dev, 
             try { r->StepAsync(); } catch (...) { r->_defer_apply = false; throw; }
         }
         r->_defer_apply = false;
+        const auto c2 = std::chrono::steady_clock::now();
         r->Sync();                                             // the only host<->device sync of the sequence
         ok = (int)(r->tracked_total - before);
+        if (timing) {
+            const auto c3 = std::chrono::steady_clock::now();
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                return std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+            fprintf(stderr, "[seq timing] frames %d: leading sync %.1f us, enqueue %.1f us, final sync %.1f us, total %.1f us\n", count,
+                    us(c0, c1), us(c1, c2), us(c2, c3), us(c0, c3));
+        }
     } else for (int k = 0; k < count; k++) {
         r->LoadFrameDevice(depth_dev[k], depth_pitch, bgr_dev[k], bgr_pitch);
         if (r->Step() != 0) ok++;

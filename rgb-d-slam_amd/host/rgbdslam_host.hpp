@@ -347,6 +347,7 @@ public:
     // take off the critical path), hence off by default.
     bool overlap = false;
     void SyncAll();                                                // main + auxiliary streams
+    void SyncIfStale();                                            // Sync() unless nothing was enqueued since the last one
     static const int HISTORY_CAP = 8192;                           // per-frame pose ring (16 floats each)
     int frames_done = 0;
     long tracked_total = 0;                                        // frames tracked so far (as of the last Sync)

@@ -690,6 +690,44 @@ def test_update_plane_partition(ctx, orc, pair, synth):
         same(a, b)
 
 
+def test_copy_segments_and_polled_synchronize(ctx, pkg):
+    """rgbdslam_copy_segments: up to four device ranges stored into pinned host memory by one launch (what RG::Sync reads the
+    pose block and the history ring segments with), 16-byte and 4-byte aligned, ragged sizes; rgbdslam_synchronize with and
+    without the polling phase returns with the data on the host."""
+    import ctypes as C
+    lib = ctx.lib
+    rng = np.random.default_rng(5)
+    for spin in (0, 5000):
+        assert lib.rgbdslam_set_sync_spin(ctx._h, spin) == 0
+        words = [33, 4096 * 16, 7, 1]                                  # pose-block-sized, a long ring segment, ragged tails
+        offs = [0, 1, 3, 0]                                            # in words: the second and third are only 4-byte aligned
+        src = [torch.from_numpy(rng.integers(0, 2 ** 31, w + 8, dtype=np.int32)).cuda() for w in words]
+        dst = [torch.full((w + 8,), -1, dtype=torch.int32).pin_memory() for w in words]
+        for n in (4, 3, 1, 0):
+            for d in dst:
+                d.fill_(-1)
+            sp = (C.c_void_p * 4)(*[s_.data_ptr() + 4 * o for s_, o in zip(src, offs)])
+            dp = (C.c_void_p * 4)(*[d_.data_ptr() + 4 * o for d_, o in zip(dst, offs)])
+            by = (C.c_size_t * 4)(*[4 * w for w in words])
+            assert lib.rgbdslam_copy_segments(ctx._h, sp, dp, by, n) == 0
+            assert lib.rgbdslam_synchronize(ctx._h) == 0
+            for k in range(4):
+                got, want = dst[k].numpy(), host(src[k])
+                o, w = offs[k], words[k]
+                if k < n:
+                    same(got[o:o + w], want[o:o + w])
+                    assert (got[:o] == -1).all() and (got[o + w:] == -1).all()      # nothing outside the range
+                else:
+                    assert (got == -1).all()
+        # argument errors (RGBDSLAM_E_ARG = 1): too many segments, a size that is no multiple of 4, a null range
+        assert lib.rgbdslam_copy_segments(ctx._h, sp, dp, by, 5) == 1
+        bad = (C.c_size_t * 4)(6, 4, 4, 4)
+        assert lib.rgbdslam_copy_segments(ctx._h, sp, dp, bad, 1) == 1
+        nul = (C.c_void_p * 4)(None, None, None, None)
+        assert lib.rgbdslam_copy_segments(ctx._h, nul, dp, by, 1) == 1
+    assert lib.rgbdslam_set_sync_spin(ctx._h, -1) == 1
+
+
 def test_argument_errors(ctx, pkg):
     lib = pkg.load()
     assert lib.rgbdslam_compute_normal(ctx._h, None, None, 480, 640, 1) == 1
