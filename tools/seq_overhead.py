@@ -55,12 +55,36 @@ def run(k, pos):
     return (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6
 
 
-run(400, 31)
+def run_frames(frames):
+    seq = rg.prepare_device_sequence([depth[i] for i in frames], [bgr[i] for i in frames])
+    torch.cuda.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ok = rg.run_device_sequence(seq)
+    torch.cuda.synchronize(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    assert ok == len(frames), (ok, len(frames))
+    return (t1 - t0) * 1e6
+
+
 print("torch.cuda.synchronize() on an idle device: %.2f us" % sync_cost())
+# the driver's frames: after the 31 set-up frames and 5 warm-up frames, pool frames 36..55 -- as one 20-frame call, and the SAME
+# frames (back and forth through 36..55) as calls of 20 and of 220, so that content does not blur the comparison
+run_frames(list(range(31, 36)))
+first = run_frames(list(range(36, 56)))
+pp, k, d = [], 55, -1
+for _ in range(2000):
+    if k + d < 36 or k + d > 55:
+        d = -d
+    k += d
+    pp.append(k)
+pos = 0
+run_frames(pp[pos:pos + 380]); pos += 380            # (19-frame legs: 380 frames end where they started, at frame 55 going down)
+print("first 20-frame call (bench's timed frames, 5 warm-up frames before): %.1f us = %.2f us/frame" % (first, first / 20))
 for rep in range(3):
-    a = run(20, 431 + 300 * rep)
-    b = run(220, 451 + 300 * rep)
-    per = (b[0] - a[0]) / 200.0
-    print("K=20: call %.1f us, sync %.1f + %.1f us | K=220: call %.1f us | steady %.2f us/frame -> fixed part of a call %.1f us"
-          % (a[0], a[1], a[2], b[0], per, a[0] - 20 * per))
+    a = run_frames(pp[pos:pos + 19] + pp[pos + 19:pos + 20]); pos += 20
+    b = run_frames(pp[pos:pos + 220]); pos += 220
+    c = run_frames(pp[pos:pos + 20]); pos += 20
+    per = (b - 0.5 * (a + c)) / 200.0
+    print("20 frames: %.1f / %.1f us; 220 frames: %.1f us; steady %.2f us/frame -> fixed part of a call %.1f us"
+          % (a, c, b, per, 0.5 * (a + c) - 20 * per))
 rg.close()
