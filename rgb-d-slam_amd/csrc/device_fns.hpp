@@ -48,9 +48,6 @@ __device__ __forceinline__ F3 normal_from_cross(F3 p, F3 dn, F3 up, F3 rt, F3 lf
     if (tot == 0) return z;
     float ft = (float)tot;
     float a0 = ((n1.x + n2.x) + n3.x) + n4.x, a1 = ((n1.y + n2.y) + n3.y) + n4.y, a2 = ((n1.z + n2.z) + n3.z) + n4.z;
-#ifdef NORMAL_DIV_COUNT                              // (A/B builds only)
-    a0 = a0 / ft; a1 = a1 / ft; a2 = a2 / ft;
-#else
     // x / 1, x / 2, x / 4 are x * 1, x * 0.5, x * 0.25 bit for bit (both are the correctly rounded value of the same real
     // number); only a count of 3 needs a division, and a pixel with exactly three valid triangles is rare (the rim of a
     // hole): the three IEEE divisions (~33 instructions of a ~330-instruction normal) run only in waves that hold one.
@@ -58,7 +55,6 @@ __device__ __forceinline__ F3 normal_from_cross(F3 p, F3 dn, F3 up, F3 rt, F3 lf
     if (__ballot(tot == 3) != 0ull) {
         a0 = (tot == 3) ? a0 / ft : a0 * inv; a1 = (tot == 3) ? a1 / ft : a1 * inv; a2 = (tot == 3) ? a2 / ft : a2 * inv;
     } else { a0 = a0 * inv; a1 = a1 * inv; a2 = a2 * inv; }
-#endif
     float nn = __builtin_sqrtf((a0 * a0 + a1 * a1) + a2 * a2);
     if (nn == 0.0f) return z;
     F3 r;
@@ -242,7 +238,6 @@ __device__ __forceinline__ void ras_draw_tri(unsigned long long *__restrict__ zb
     // within 2^14 + 256 of the edge's start: |w| < 2 * 2^14 * (2^14 + 256) < 2^30), so the SAME integers are formed and stepped
     // in 32 bits: one add instead of two per edge and pixel, one conversion to double instead of a 64-bit one.  The area
     // (sum of the three) fits likewise.  Same values, same doubles, same depth bits; larger triangles take the 64-bit loop.
-#ifndef RAS_NO_FAST32                                 // (A/B builds only: tools/make_variant.sh with EXTRA=-DRAS_NO_FAST32)
     if (xmx - xmn <= 16384 && ymx - ymn <= 16384) {
         int row[3], sx[3], sy[3];
         bool tl[3];
@@ -273,7 +268,6 @@ __device__ __forceinline__ void ras_draw_tri(unsigned long long *__restrict__ zb
         }
         return;
     }
-#endif
     // edge k runs from vertex (k+1)%3 to vertex (k+2)%3 (as in ras_cover)
     long long row[3], sx[3], sy[3];
     bool tl[3];

@@ -447,11 +447,7 @@ __device__ __forceinline__ bool seg3_stage(const SegArgsT<LT> &a, const SegTileR
 template <typename LT>
 __device__ __forceinline__ LT seg3_passes(const SegArgsT<LT> &a, const int i0, const int j0, const int tid, SegTileLdsT<LT> &S,
                                           const bool any_label) {
-#ifdef SEG3_NOQUEUE                                  // (timing experiments only: the passes never run)
-    const int nq = 0;
-#else
     const int nq = any_label ? (int)S.qn : 0;        // uniform
-#endif
     LT *const L = &S.lab[0][0];
     if (nq > 0) {
         const float *__restrict__ V = a.VMap;

@@ -334,7 +334,6 @@ __device__ __forceinline__ void icp_end_step(const IcpState *st, const IcpEndArg
 // LDS of one workgroup of the iteration kernels
 struct IcpShared {
     float (&part)[2][ICP_MAX_WAVES][27];   // block sums of a round; two sets, so that a round needs ONE barrier (below)
-    float (&accB)[27];                     // chain t + 256's sum on its way to wave 0
     float (&tr)[ICP_MAX_WAVES][27 * 8];
     float (&fin)[27];
     float (&solve_sh)[2];
@@ -343,13 +342,12 @@ struct IcpShared {
 };
 #define ICP_SHARED_DECL(S)                                                       \
     __shared__ float part_[2][ICP_MAX_WAVES][27];                                \
-    __shared__ float accB_[27];                                                  \
     __shared__ __attribute__((aligned(16))) float tr_[ICP_MAX_WAVES][27 * 8];    \
     __shared__ float fin_[27];                                                   \
     __shared__ float solve_sh_[2];                                               \
     __shared__ IcpState sst_;                                                    \
     __shared__ float spose_[24];                                                 \
-    IcpShared S = {part_, accB_, tr_, fin_, solve_sh_, sst_, spose_}
+    IcpShared S = {part_, tr_, fin_, solve_sh_, sst_, spose_}
 
 // One iteration as seen by workgroup blockIdx.x.  LOOP = called from the persistent k_icp_loop: the
 // state changes while the kernel runs, so it is read and written with agent-scope atomics (plain
@@ -380,8 +378,6 @@ template <bool LOOP, bool XCHG>
 __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpShared &S, IcpLoopCtl lc, const int tid, const int t,
                                               IcpModelCache &mc) {
     float (&part)[2][ICP_MAX_WAVES][27] = S.part;
-    float (&accB)[27] = S.accB;                     // only the -DICP_ACC_TWO_WAVES form (A/B) uses it
-    (void)accB;
     float (&tr)[ICP_MAX_WAVES][27 * 8] = S.tr;
     float (&fin)[27] = S.fin;
     float (&solve_sh)[2] = S.solve_sh;
@@ -472,13 +468,9 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         inside = mc.in0;
         mp = mc.r0;
     } else if (active) { locate(k); mp = icp_load_model(idx, a.VMap_prev, a.NMap_prev, a.RGBD_prev); }
-#ifdef ICP_LOOP_ALL_BARRIERS
-    __syncthreads();
-#else
     // persistent loop after step 0: nothing above has written to LDS, and the barrier behind the hand-over poll (k_icp_loop)
     // already stands between the new state in sst and its readers
     if (!LOOP || a.first_launch) __syncthreads();
-#endif
     if (!LOOP && (sst.fail || (a.iter > 0 && sst.cvg))) {   // converged / failed earlier: the whole grid leaves
         if (a.final_launch && t == 0 && tid == 0) {
             IcpEndArgs e = {a.pose_state_rw, a.status, a.pb, a.history, a.frame_index};
@@ -541,15 +533,9 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             IcpRow q;
 #pragma unroll
             for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
-#ifndef ICP_REQUEST_IN_ROUND
             if (LOOP && r == 0 && want_next && t == nwg - 1) request_next();   // the tail: see below
-#endif
             IcpProj pr = icp_project(mp, Rc, tc3, in4, a.n, a.m);
             IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
-#ifdef ICP_REQUEST_IN_ROUND
-            if (LOOP && r == 0 && want_next) { request_next(); icp_pin_gather_after_prefetch(cu); }
-            else
-#endif
             icp_pin_gather(cu);
             int proj = -1;
             const bool ok = icp_rows(mp, pr, cu, in4, a.distThres, a.angleThres, inside, q, proj);
@@ -578,29 +564,16 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             float sum = fold27(v, lane, tr[wave]);
             if (lane < 27) part[r & 1][wave][lane] = sum;
         }
-#ifdef ICP_REQUEST_IN_ROUND
-        else if (LOOP && r == 0 && want_next) request_next();   // a wave without a block at this level may have one at the next
-#else
         else if (LOOP && r == 0 && want_next && t == nwg - 1) request_next();
-#endif
         // ONE barrier per round: the block sums alternate between two sets, and the two accumulating waves pass the next
         // round's barrier only after they have read this round's set -- nobody can overwrite it before (round r + 2)
         __syncthreads();
-#ifdef ICP_ACC_TWO_WAVES
-        if (wv == 0 && lane < 27) {                   // the first wave of each chain adds its chain's blocks in chain order
-            int cnt = min(ICP_CHAIN_WAVES, chain_len - r * ICP_CHAIN_WAVES);
-            for (int w = 0; w < cnt; w++) acc += part[r & 1][wave + w][lane];
-        }
-#else
         // wave 0 adds BOTH chains' blocks in chain order, chain t in lanes 0..26 and chain t + 256 in lanes 32..58: the two
         // sums meet through a lane exchange below instead of an LDS word and one more workgroup barrier per step
         if (wave == 0 && (lane & 31) < 27) {
             const int hb = lane >> 5;
             const int len_h = max(0, (nblk - (t + ICP_WGS * hb) + ICP_CHAINS - 1) / ICP_CHAINS);
             const int cnt = min(ICP_CHAIN_WAVES, len_h - r * ICP_CHAIN_WAVES);
-#ifdef ICP_ACC_LOOP
-            for (int w = 0; w < cnt; w++) acc += part[r & 1][hb * ICP_CHAIN_WAVES + w][lane & 31];
-#else
             // all six slots are read at once (one LDS round trip instead of one per block, in a loop whose trip count differs
             // between the lanes) and added in chain order under selects; a slot beyond the chain's end holds an older round's sum
             float pv[ICP_CHAIN_WAVES];
@@ -608,30 +581,19 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             for (int w = 0; w < ICP_CHAIN_WAVES; w++) pv[w] = part[r & 1][hb * ICP_CHAIN_WAVES + w][lane & 31];
 #pragma unroll
             for (int w = 0; w < ICP_CHAIN_WAVES; w++) { const float nx = acc + pv[w]; acc = w < cnt ? nx : acc; }
-#endif
         }
-#endif
     }
     long long ts1 = a.timing ? wall_clock64() : 0;
     // offset 256 of reduce<512> (ICP.cu:35): chain t + chain t+256, added here instead of in the tail (a chain that does
     // not exist contributes the 0 the reference's memset leaves in its place)
-#ifdef ICP_ACC_TWO_WAVES
-    if (wave == ICP_CHAIN_WAVES && lane < 27) accB[lane] = acc;
-    __syncthreads();
-#endif
     // Publish the 27 sums to the other XCDs without an L2 write-back and without waiting for an acknowledgement: ONE
     // wave-wide agent-scope (write-through) store puts them into line icp_chain_line(t) of the chain buffer, laid out
     // like the state line of the persistent loop -- term k in slot k + k/7, and a.seq (unique per launch / step) in the
     // last slot of every 32-byte sector.  The reader checks those sequence words (below) instead of anyone waiting.
     if (wave == 0) {
         const int k = lane - (lane >> 3);             // term held by slot `lane`
-#ifdef ICP_ACC_TWO_WAVES
-        const float out = acc + accB[lane < 27 ? lane : 0];
-        const float v = __shfl(out, k < 27 ? k : 0);
-#else
         const int kq = k < 27 ? k : 0;
         const float v = __shfl(acc, kq) + __shfl(acc, kq + 32);   // chain t + chain t + 256 (a chain that does not exist has added nothing)
-#endif
         unsigned int word = ((lane & 7) == 7) ? a.seq : __float_as_uint(v);
         if (a.line_check) {                               // slot 30: integrity word of the 27 sums
             const unsigned int chk = icp_line_xor_lo(word, lane);
@@ -640,7 +602,6 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
         if (lane < 32)
             __hip_atomic_store((unsigned int *)a.chains + 32 * icp_chain_line(t) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#ifndef ICP_REQUEST_IN_ROUND
     // The next level's samples are requested HERE, behind the step's last use of a loaded value, not inside the match round:
     // there the branch round the six loads joined paths with different numbers of requests in flight, and the wait counts
     // the compiler places behind such a join are those of the path with the fewest -- the first step of a level waited for
@@ -648,7 +609,6 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
     // exception: it is about to poll the lines, and loads return in order, so it has made its requests BEFORE its gather
     // (above) -- half a microsecond ahead of everybody else's step, which the hand-over it does not need pays for.
     if (LOOP && want_next && t != nwg - 1) request_next();
-#endif
     long long ts2 = a.timing ? wall_clock64() : 0;
     // No arrival counter: the LAST workgroup of the step (it is dispatched last and owns the shortest chains) is the tail.
     // It re-reads the published lines until every one carries this step's sequence words -- one round trip after the
@@ -908,9 +868,6 @@ void k_icp_loop(IcpLoopArgs L) {
             a.frame_index = L.frame_index;
             icp_iter_body<true, XCHG>(a, S, IcpLoopCtl{pub, L.epoch_base, s, start + a.max_iter + 2, L.nsteps, CHECK}, tid, t, mc);
         }
-#ifdef ICP_LOOP_ALL_BARRIERS
-        __syncthreads();                               // every thread is done with S
-#endif
         // No barrier in front of the poll: wave 0 writes the new state into sst_, whose readers (the pose reads at the top of
         // the step) all lie in front of the step's round barriers, which wave 0 has passed too; the tail's other LDS traffic
         // (tree, solve) ends at barriers inside icp_iter_body.
@@ -1035,15 +992,6 @@ __device__ __forceinline__ float lane_read(float v, int src) {
 // pivot are never looked at again and are not exchanged).
 __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
     float a[6];
-#ifdef ICP_DET_NO_PIN
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        float v = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 6; r++) v = (lane == r) ? SYM_A(sums, r, k) : v;
-        a[k] = v;
-    }
-#else
     // the 21 matrix entries in ONE LDS round trip (left alone the reads are issued and waited for in five or six batches,
     // each next to its first use), then the rows are picked by lane
     float sv[21];
@@ -1060,7 +1008,6 @@ __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
         for (int r = 0; r < 6; r++) v = (lane == r) ? at(r, k) : v;
         a[k] = v;
     }
-#endif
     float det = 1.0f;
     bool done = false;
 #pragma unroll
@@ -1081,16 +1028,10 @@ __device__ __forceinline__ float wave_det6(const float *sums, int lane) {
             a[k] = (lane == c) ? vp : ((lane == p) ? vc : a[k]);   // exchange rows c and p (no-op when p == c)
         }
         float piv = rowp[c];
-#ifdef ICP_SOLVE_EARLY_EXIT
-        if (p != c) det = -det;
-        det = det * piv;
-        if (piv == 0.0f || piv != piv) return det;
-#else
         // (no exit inside the elimination either: the value the serial algorithm returns at a zero / NaN pivot is frozen)
         const float dn = (p != c ? -det : det) * piv;
         det = done ? det : dn;
         done |= (piv == 0.0f || piv != piv);
-#endif
         if (lane > c && lane < 6) {
             float f = a[c] / piv;
 #pragma unroll
@@ -1154,11 +1095,9 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
         Arow[k] = sums[i * 7 - (i * (i - 1)) / 2 + (j - i)];     // SYM_A(sums, r, k) for r < 6, b[k] for r == 6
         Lr[k] = 0.0f;
     }
-#ifndef ICP_SOLVE_NO_PIN
     // all six reads in flight before the first column: left alone, each is sunk to the column that uses it and becomes an
     // LDS round trip of its own on the serial path
     asm volatile("" : "+v"(Arow[0]), "+v"(Arow[1]), "+v"(Arow[2]), "+v"(Arow[3]), "+v"(Arow[4]), "+v"(Arow[5]));
-#endif
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         float s = Arow[k], w = Arow[k], Lk[6];
@@ -1169,14 +1108,10 @@ __device__ __forceinline__ int wave_llt_solve6(const float *sums, int lane, floa
             w = w - Lr[p] * Lk[p];                               // meaningful in lanes r > k (lane 6: the forward substitution)
         }
         const float sk = lane_read(s, k);
-#ifdef ICP_SOLVE_EARLY_EXIT
-        if (!(sk > 0.0f)) return 1;
-#else
         // no exit inside the factorisation: a non-positive pivot is remembered and the arithmetic goes on (on values nobody
         // will use) -- six early exits cut the unrolled code into seven basic blocks, and the scheduler could not move a
         // column's products with the columns before the last one into the shadow of that one's square root and division
         fail |= !(sk > 0.0f);
-#endif
         const float lkk = __builtin_sqrtf(sk);
         Lr[k] = (r == k) ? lkk : w / lkk;
     }
@@ -1281,9 +1216,6 @@ __device__ __forceinline__ float icp_pose_update_wave(const IcpState *st, const 
     // iteration of level 0 the pair is left untouched: the track-loss test reads the LAST
     // uploaded pair, not the final estimate (RG.cpp:910).
     float cv = old_word;
-#ifdef ICP_SOLVE_EARLY_EXIT
-    if (!cvg || lvl > 0)
-#endif
     {
         float nR[9], nt[3];
 #pragma unroll
@@ -1295,11 +1227,7 @@ __device__ __forceinline__ float icp_pose_update_wave(const IcpState *st, const 
         const float r2 = i == 0 ? nR[6] : (i == 1 ? nR[7] : nR[8]);
         float cn = (r0 * p0 + r1 * p1) + r2 * p2;                                        // RG.cpp:851 | 852
         if (is_t) cn = cn + (i == 0 ? nt[0] : (i == 1 ? nt[1] : nt[2]));
-#ifdef ICP_SOLVE_EARLY_EXIT
-        cv = cn;
-#else
         cv = (!cvg || lvl > 0) ? cn : old_word;                                          // (a select, not a branch round twelve lane reads)
-#endif
     }
     return role_b ? cv : nv;
 }
@@ -1324,14 +1252,10 @@ __device__ __forceinline__ void icp_solve_step(IcpState *st, IcpState *out, cons
         word = ((const float *)st)[kr];
         iters = st->iters; lvl_iters = st->lvl_iters; cvg = st->cvg;
         llt_fail = wave_llt_solve6(sums, lane, x);             // RG.cpp:873 (wave-uniform result)
-#ifdef ICP_SOLVE_EARLY_EXIT
-        if (!llt_fail) new_word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, new_cvg);
-#else
         // unconditional (a failed factorisation's update is computed on garbage and dropped below): no branch between the
         // solve and the update, so the quaternion's f64 chain -- it only needs x[3..5], the FIRST results of the backward
         // substitution -- is scheduled beside the rest of the substitution
         new_word = icp_pose_update_wave(st, x, pose_state, lvl, iter, max_iter, thr_alpha, thr_tr, kr, word, new_cvg);
-#endif
     }
     __syncthreads();
     if (wave != 0) return;
