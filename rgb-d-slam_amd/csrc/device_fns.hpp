@@ -398,21 +398,42 @@ __device__ __forceinline__ LT segment_pixel(const LT *__restrict__ in, const flo
 
 // ---- D1/Primitive.cu:31-93 VertexFromBumpKernel: one Bump cell -> vertex, colour, packed mask ----------
 struct BumpCell { float3 v; float4 c, k; };
-struct BumpParam { float p[14]; };
+// inv4 / inv5 = the correctly rounded reciprocals of p[4], p[5] as doubles, fast = every quotient of decode_cell may be formed
+// from a reciprocal (below); both are functions of the plane, computed once per thread by load_param
+struct BumpParam { float p[14]; double inv4, inv5; bool fast; };
 // u8 / 255.0 (Primitive.cu:80-82,90): (float)((double)x / C) == x / (float)C for float x -- double
 // rounding is innocuous for division (53 >= 2*24 + 2)
 __device__ __forceinline__ float unorm8(uint8_t x) { return (float)x / 255.0f; }
+// The correctly rounded quotient a / b from y = RN(1 / b): q = RN(a y) is within an ulp, r = a - b q is exact in one FMA, and
+// RN(q + r y) is RN(a / b) (Markstein's theorem; it needs y correctly rounded, b's significand not all ones, and no overflow,
+// underflow or non-finite value on the way -- the callers' conditions).  Three instructions where the IEEE division sequence
+// has eleven (f32) or fifteen (f64); the explicit FMAs are not contractions (-ffp-contract=off only governs a * b + c).
+// Checked against exact rational arithmetic for every u16 / 60000.0f and u16 / 2000.0 and 600 000 random quotients of the
+// other two kinds; the byte- and word-exhaustive decode tests compare the results with the oracle's divisions.
+__device__ __forceinline__ float quot_rcp(float a, float b, float y) { float q = a * y; return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q); }
+__device__ __forceinline__ double quot_rcp(double a, double b, double y) { double q = a * y; return __builtin_fma(__builtin_fma(-b, q, a), y, q); }
 // UNORM = functor returning x/255 for a byte (direct division, or a 256-entry LDS table)
 template <typename UNORM>
 __device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16_t b2, uint8_t r, uint8_t g, uint8_t b, uint8_t mk,
                                                 const BumpParam &P, float fi, float fj, UNORM unorm) {
     const float *param = P.p;
     BumpCell o;
-    float s0 = (float)b0 / 60000.0f;
-    float s1 = (float)b1 / 60000.0f;
-    float x = (float)((double)(fi + s0) * 2.0 / (double)param[4] + (double)param[6]);
-    float y = (float)((double)(fj + s1) * 2.0 / (double)param[5] + (double)param[7]);
-    float d = (float)((double)param[3] + (((double)(float)b2 / 2000.0) - 15.0));
+    float x, y, d;
+    if (P.fast) {                                               // (uniform: a property of the plane)
+        // u16 / 60000.0f and u16 / 2000.0: bounded numerators, constant denominators.  (fi + s0) * 2 is 0 or in [2^-15, 2^18],
+        // p[4], p[5] are finite and in [2^-40, 2^60] in magnitude: every quotient and residual is finite and normal.
+        const float s0 = quot_rcp((float)b0, 60000.0f, 1.0f / 60000.0f);
+        const float s1 = quot_rcp((float)b1, 60000.0f, 1.0f / 60000.0f);
+        x = (float)(quot_rcp((double)(fi + s0) * 2.0, (double)param[4], P.inv4) + (double)param[6]);
+        y = (float)(quot_rcp((double)(fj + s1) * 2.0, (double)param[5], P.inv5) + (double)param[7]);
+        d = (float)((double)param[3] + (quot_rcp((double)(float)b2, 2000.0, 1.0 / 2000.0) - 15.0));
+    } else {
+        const float s0 = (float)b0 / 60000.0f;
+        const float s1 = (float)b1 / 60000.0f;
+        x = (float)((double)(fi + s0) * 2.0 / (double)param[4] + (double)param[6]);
+        y = (float)((double)(fj + s1) * 2.0 / (double)param[5] + (double)param[7]);
+        d = (float)((double)param[3] + (((double)(float)b2 / 2000.0) - 15.0));
+    }
     o.v.x = (x * param[8] + y * param[11]) + d * param[0];
     o.v.y = (x * param[9] + y * param[12]) + d * param[1];
     o.v.z = (x * param[10] + y * param[13]) + d * param[2];
@@ -420,9 +441,16 @@ __device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16
     o.c.y = unorm(g);
     o.c.z = unorm(b);
     o.c.w = 1.0f;
-    o.k.x = (float)((10.0 + (double)o.v.x) / 20.0);
-    o.k.y = (float)((10.0 + (double)o.v.y) / 20.0);
-    o.k.z = (float)((10.0 + (double)o.v.z) / 20.0);
+    if (P.fast) {
+        // |v| < 2^123 under the bounds of load_param: 10 + v is 0 or at least 2^-21 in magnitude, and finite
+        o.k.x = (float)quot_rcp(10.0 + (double)o.v.x, 20.0, 1.0 / 20.0);
+        o.k.y = (float)quot_rcp(10.0 + (double)o.v.y, 20.0, 1.0 / 20.0);
+        o.k.z = (float)quot_rcp(10.0 + (double)o.v.z, 20.0, 1.0 / 20.0);
+    } else {
+        o.k.x = (float)((10.0 + (double)o.v.x) / 20.0);
+        o.k.y = (float)((10.0 + (double)o.v.y) / 20.0);
+        o.k.z = (float)((10.0 + (double)o.v.z) / 20.0);
+    }
     o.k.w = unorm(mk);
     if (mk < 11 && mk != 1) {                                   // Primitive.cu:47: empty cell -> zeros (branch-free select)
         o.v.x = o.v.y = o.v.z = 0.0f;
@@ -433,8 +461,16 @@ __device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16
 }
 __device__ __forceinline__ BumpParam load_param(const float *__restrict__ param) {
     BumpParam P;
+    bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 14; k++) P.p[k] = param[k];
+    for (int k = 0; k < 14; k++) {
+        P.p[k] = param[k];
+        ok = ok && __builtin_fabsf(P.p[k]) <= 0x1p60f;          // finite and bounded (NaN fails the comparison)
+    }
+    ok = ok && __builtin_fabsf(P.p[4]) >= 0x1p-40f && __builtin_fabsf(P.p[5]) >= 0x1p-40f;
+    P.fast = ok;
+    P.inv4 = 1.0 / (double)P.p[4];
+    P.inv5 = 1.0 / (double)P.p[5];
     return P;
 }
 

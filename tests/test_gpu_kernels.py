@@ -457,25 +457,50 @@ def test_update_and_decode(ctx, orc, pair, synth):
         same(host(outs[2][k]), rk)
 
 
-def test_decode_all_byte_and_word_values(ctx, orc):
-    """Bump codec decode over every u8 colour/mask value and a sweep of u16 values: pins the claim
-    that the f32 divisions used on the device equal the reference's divide-in-double-then-round."""
+_DECODE_PARAMS = {
+    "typical": [0.3, -0.5, 0.81, -1.7, 500.0, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5],
+    "odd scales": [0.3, -0.5, 0.81, 2.25, 333.3, 0.73, 7.0, -3.0, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5],
+    "negative scales": [1.0, 0.0, 0.0, -14.9, -1023.9999, -57.0, 0.0, 0.0, 0.6, 0.8, 0.0, -0.8, 0.6, 0.0],
+    # outside the range in which the device forms its quotients from reciprocals (|p| <= 2^60, |p[4]|, |p[5]| >= 2^-40):
+    # the plain divisions run, and the results -- infinities and NaN included -- are still the oracle's
+    "scale below 2^-40": [0.3, -0.5, 0.81, -1.7, 1e-20, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5],
+    "scale zero": [0.3, -0.5, 0.81, -1.7, 500.0, 0.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5],
+    "huge axis": [0.3, -0.5, 0.81, -1.7, 500.0, 500.0, -0.51, 0.27, 3e30, 0.1, -0.42, 0.2, 0.84, 0.5],
+    "infinite offset": [0.3, -0.5, 0.81, np.inf, 500.0, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5],
+    "nan": [0.3, np.nan, 0.81, -1.7, 500.0, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5],
+}
+
+
+@pytest.mark.parametrize("which", list(_DECODE_PARAMS))
+def test_decode_all_byte_and_word_values(ctx, orc, which):
+    """Bump codec decode over every u8 colour/mask value and EVERY u16 value of each of the three channels: pins the claim
+    that the quotients the device forms -- from correctly rounded reciprocals and an exact FMA residual where the plane's
+    parameters allow it (device_fns.hpp: quot_rcp), by plain division otherwise -- are the reference's divisions bit for bit."""
     N = 256
     rng = np.random.default_rng(9)
     bump = rng.integers(0, 65536, (N, N, 3)).astype(np.uint16)
-    bump[:, :, 0] = (np.arange(N * N).reshape(N, N) * 1) % 65536            # all 65536 values of the first channel
+    sweep = (np.arange(N * N).reshape(N, N) % 65536).astype(np.uint16)
+    bump[:, :, 0] = sweep                                                     # all 65536 values of every channel
+    bump[:, :, 1] = sweep.T
+    bump[:, :, 2] = sweep[::-1, ::-1]
     rgbb = rng.integers(0, 256, (N, N, 3)).astype(np.uint8)
     rgbb[0, :, 0] = np.arange(256)
     mask = (np.arange(N * N).reshape(N, N) % 256).astype(np.uint8)
-    param = np.array([0.3, -0.5, 0.81, -1.7, 500.0, 500.0, -0.51, 0.27, 0.9, 0.1, -0.42, 0.2, 0.84, 0.5], np.float32)
+    param = np.asarray(_DECODE_PARAMS[which], np.float32)
     g = [dev(bump), dev(rgbb), dev(mask), dev(param)]
     outs = [[torch.empty(N, N, ch, device="cuda")] for ch in (3, 4, 4)]
     ctx.vertex_from_bump_batch(_ptr_table(outs[0]), _ptr_table(outs[1]), _ptr_table(outs[2]), _ptr_table([g[0]]), _ptr_table([g[1]]),
                                _ptr_table([g[2]]), _ptr_table([g[3]]), 0, 1, N, N)
-    rv, rc, rk = orc.vertex_from_bump(bump, rgbb, mask, param, 1)
+    with np.errstate(all="ignore"):
+        rv, rc, rk = orc.vertex_from_bump(bump, rgbb, mask, param, 1)
     same(host(outs[0][0]), rv)
     same(host(outs[1][0]), rc)
     same(host(outs[2][0]), rk)
+    # the per-plane kernel (one cell per thread) shares the device function
+    v, c, k4 = (torch.empty(N, N, ch, device="cuda") for ch in (3, 4, 4))
+    ctx.vertex_from_bump(v, c, k4, g[0], g[1], g[2], g[3], N, N, 1)
+    same(host(v), rv)
+    same(host(k4), rk)
 
 
 def test_preprocess_fused_all_byte_values(ctx, orc, synth):
