@@ -16,7 +16,11 @@
 #define TILE_W 64
 #define TILE_H 4
 
-struct CalibV { float v[11]; };
+// v = the reference's 11 calibration floats (fx, fy, cx, cy, ..., [9] depth scale, [10] depth factor).  Derived on the host by
+// rgbdslam_set_calibration_matrix: inv_fx / inv_fy = the correctly rounded reciprocals of the focal lengths, s = v[9] / v[10], and
+// fast = the per-pixel quotients by fx, fy and the constant 100 may be formed from reciprocals (device_fns.hpp: quot_rcp) --
+// every value finite and in the range where no intermediate overflows or underflows; otherwise the kernels divide.
+struct CalibV { float v[11]; float inv_fx, inv_fy, s; int fast; };
 struct PoseV  { float v[16]; };
 
 // Device-resident state of the Gauss-Newton loop (RG::AlignFrameGaussNewton, D1/RG.cpp:797-932).

@@ -4,6 +4,7 @@
 #include <new>
 #include <chrono>
 #include <string.h>
+#include <math.h>
 #include <stdlib.h>
 
 extern "C" const char *rgbdslam_version(void) { return "rgbdslam-hip 0.1 (gfx950)"; }
@@ -171,7 +172,17 @@ extern "C" int rgbdslam_copy_segments(rgbdslam_ctx *ctx, const void *const *src_
 
 extern "C" int rgbdslam_set_calibration_matrix(rgbdslam_ctx *ctx, const float *calib11) {
     if (!ctx || !calib11) return RGBDSLAM_E_ARG;
-    for (int k = 0; k < 11; k++) ctx->calib.v[k] = calib11[k];
+    CalibV &c = ctx->calib;
+    for (int k = 0; k < 11; k++) c.v[k] = calib11[k];
+    // host IEEE divisions: the same correctly rounded values the kernels' divisions give
+    c.inv_fx = 1.0f / c.v[0]; c.inv_fy = 1.0f / c.v[1]; c.s = c.v[9] / c.v[10];
+    auto focal_ok = [](float f) {                  // finite, 2^-20 <= |f| <= 2^40, significand not all ones (Markstein's condition)
+        uint32_t b; memcpy(&b, &f, 4);
+        return fabsf(f) >= 0x1p-20f && fabsf(f) <= 0x1p40f && (b & 0x7FFFFFu) != 0x7FFFFFu;
+    };
+    auto centre_ok = [](float x) { return x == 0.0f || (fabsf(x) >= 0x1p-60f && fabsf(x) <= 0x1p20f); };
+    c.fast = focal_ok(c.v[0]) && focal_ok(c.v[1]) && centre_ok(c.v[2]) && centre_ok(c.v[3]) &&
+             (c.s == 0.0f || (fabsf(c.s) >= 0x1p-40f && fabsf(c.s) <= 0x1p40f));
     ctx->have_calib = true;
     return 0;
 }

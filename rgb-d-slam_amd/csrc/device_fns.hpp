@@ -4,15 +4,47 @@
 #pragma once
 #include "common.hpp"
 
+// The correctly rounded quotient a / b from y = RN(1 / b): q = RN(a y) is within an ulp, r = a - b q is exact in one FMA, and
+// RN(q + r y) is RN(a / b) (Markstein's theorem; it needs y correctly rounded, b's significand not all ones, and no overflow,
+// underflow or non-finite value on the way -- the callers' conditions).  Three instructions where the IEEE division sequence
+// has eleven (f32) or fifteen (f64); the explicit FMAs are not contractions (-ffp-contract=off only governs a * b + c).
+// Checked against exact rational arithmetic for every u16 / 60000.0f and u16 / 2000.0 and 600 000 random quotients of the
+// other two kinds; the byte- and word-exhaustive decode tests compare the results with the oracle's divisions.
+__device__ __forceinline__ float quot_rcp(float a, float b, float y) { float q = a * y; return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q); }
+__device__ __forceinline__ double quot_rcp(double a, double b, double y) { double q = a * y; return __builtin_fma(__builtin_fma(-b, q, a), y, q); }
+// x / 255.0f for a byte and x / 3.0f for a sum of three such quotients (0 or in [1/255, 3]): constant denominators, bounded
+// numerators -- the first checked for all 256 bytes, the second for all 16.7 M sums (tools/markstein_check.py)
+__device__ __forceinline__ float div255(float x) { return quot_rcp(x, 255.0f, 1.0f / 255.0f); }
+__device__ __forceinline__ float div3_unit(float x) { return quot_rcp(x, 3.0f, 1.0f / 3.0f); }
+// (k - cx) / fx and (k - cy) / fy for a pixel index k < 65536, and the depth scale: from the host's reciprocals where the
+// calibration allows it (CalibV::fast, uniform): |k - c| is 0 or in [2^-60, 2^21], the quotient and its residual are normal
+__device__ __forceinline__ float col_over_fx(int j, const CalibV &c) {
+    const float a = (float)j - c.v[2];
+    if (c.fast) return quot_rcp(a, c.v[0], c.inv_fx);
+    return a / c.v[0];
+}
+__device__ __forceinline__ float row_over_fy(int i, const CalibV &c) {
+    const float a = (float)i - c.v[3];
+    if (c.fast) return quot_rcp(a, c.v[1], c.inv_fy);
+    return a / c.v[1];
+}
+__device__ __forceinline__ float depth_scale(const CalibV &c) { return c.fast ? c.s : c.v[9] / c.v[10]; }
+// (float)((double)x / 100.0) == x / 100.0f for a float x (double rounding is innocuous for a quotient: 53 >= 2 * 24 + 2); for
+// a finite x that is 0 or at least 2^-60 in magnitude -- a metric depth of the calibrated range -- from the reciprocal
+__device__ __forceinline__ float depth_over_max(float x, const CalibV &c) {
+    if (c.fast) return quot_rcp(x, (float)SLAM_MAX_DEPTH, 1.0f / (float)SLAM_MAX_DEPTH);
+    return (float)((double)x / SLAM_MAX_DEPTH);
+}
+
 // ---- D1/Kernel.cu:33-52 VertexMapKinectKernel: vertex of pixel (i, j) from raw depth d -----------
 __device__ __forceinline__ F3 vertex_from_depth(uint16_t d, int i, int j, const CalibV &c) {
     F3 r; r.x = r.y = r.z = 0.0f;
     if (d == 0) return r;
-    float s = c.v[9] / c.v[10];
+    float s = depth_scale(c);
     float fd = (float)d;
     float sd = s * fd;
-    r.x = sd * (((float)j - c.v[2]) / c.v[0]);
-    r.y = sd * (((float)i - c.v[3]) / c.v[1]);
+    r.x = sd * col_over_fx(j, c);
+    r.y = sd * row_over_fy(i, c);
     r.z = (-s) * fd;
     return r;
 }
@@ -85,8 +117,7 @@ __device__ __forceinline__ void pin_loaded(float4 &a) { asm volatile("" : "+v"(a
 // ---- D1/Kernel.cu:440-526 MergeDepthOffKernel: new (.w, mask) of one pixel -------------------------
 // returns the new .w; newmask < 0 = mask unchanged
 __device__ __forceinline__ float merge_pixel(float w_old, uint16_t d, uint8_t mask_old, const CalibV &c, int &newmask) {
-    float ds = c.v[9], factor = c.v[10];
-    float dv = (ds / factor) * (float)d;
+    float dv = depth_scale(c) * (float)d;
     float dp = (float)((double)w_old * SLAM_MAX_DEPTH);
     float mv = (float)((double)(float)mask_old - 10.0);
     const float mt = 1.0f;
@@ -94,9 +125,9 @@ __device__ __forceinline__ float merge_pixel(float w_old, uint16_t d, uint8_t ma
     newmask = -1;
     if ((double)dv < 0.1) {
     } else if ((double)dp < 0.1 || __builtin_fabs((double)mv + 9.0) < 0.01) {
-        w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
+        w = depth_over_max(dv, c); newmask = (int)(uint8_t)((double)mt + 10.0);
     } else if ((double)dv < ((double)dp - SLAM_MAXTOLERANCE)) {
-        w = (float)((double)dv / SLAM_MAX_DEPTH); newmask = (int)(uint8_t)((double)mt + 10.0);
+        w = depth_over_max(dv, c); newmask = (int)(uint8_t)((double)mt + 10.0);
     } else {
         double mx = 1.0 > 1.0 * (double)dv ? 1.0 : 1.0 * (double)dv;
         if ((double)dv > ((double)dp + mx * SLAM_MAXTOLERANCE)) {
@@ -104,7 +135,7 @@ __device__ __forceinline__ float merge_pixel(float w_old, uint16_t d, uint8_t ma
         } else {
             float am = __builtin_fabsf(mv);
             float avg = (dv * mt + am * dp) / (mt + am);
-            w = (float)((double)avg / SLAM_MAX_DEPTH);
+            w = depth_over_max(avg, c);                          // (both depths are at least 0.1 here, or avg is NaN and stays NaN)
             double mk = (double)(mt + am) + 10.0;
             if (mk > 255.0) mk = 255.0;
             newmask = (int)(uint8_t)mk;
@@ -117,16 +148,16 @@ __device__ __forceinline__ float merge_pixel(float w_old, uint16_t d, uint8_t ma
 __device__ __forceinline__ F3 vertex_from_w(float w, int i, int j, const CalibV &c) {
     double z = (double)w * SLAM_MAX_DEPTH;
     F3 r;
-    r.x = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)j - c.v[2]) / c.v[0]));
-    r.y = (w == 0.0f) ? 0.0f : (float)(z * (double)(((float)i - c.v[3]) / c.v[1]));
+    r.x = (w == 0.0f) ? 0.0f : (float)(z * (double)col_over_fx(j, c));
+    r.y = (w == 0.0f) ? 0.0f : (float)(z * (double)row_over_fy(i, c));
     r.z = (float)((double)(-w) * SLAM_MAX_DEPTH);
     return r;
 }
 
 // ---- D1/Kernel.cu:783-802 AddZBUFFOffKernel: .w of the seeded model ---------------------------------
 __device__ __forceinline__ float zbuff_w(uint16_t d, const CalibV &c) {
-    float z = (c.v[9] / c.v[10]) * (float)d;
-    return ((double)z > SLAM_MAX_DEPTH || (double)z < 0.0) ? 0.0f : (float)((double)z / SLAM_MAX_DEPTH);
+    float z = depth_scale(c) * (float)d;
+    return ((double)z > SLAM_MAX_DEPTH || (double)z < 0.0) ? 0.0f : depth_over_max(z, c);
 }
 
 // ---- D1/Kernel.cu:345-379 TransformVertexMapKernel: .w written next to a transformed vertex ---------
@@ -337,8 +368,8 @@ __device__ __forceinline__ void quad_vertex_ids(uint32_t q, const uint32_t *__re
 __device__ __forceinline__ F3 vertex_from_texel(float w, int i, int j, const CalibV &c) {
     float z = (float)((double)w * SLAM_MAX_DEPTH);
     F3 r;
-    r.x = z * (((float)j - c.v[2]) / c.v[0]);
-    r.y = z * (((float)i - c.v[3]) / c.v[1]);
+    r.x = z * col_over_fx(j, c);
+    r.y = z * row_over_fy(i, c);
     r.z = -z;
     return r;
 }
@@ -403,15 +434,7 @@ struct BumpCell { float3 v; float4 c, k; };
 struct BumpParam { float p[14]; double inv4, inv5; bool fast; };
 // u8 / 255.0 (Primitive.cu:80-82,90): (float)((double)x / C) == x / (float)C for float x -- double
 // rounding is innocuous for division (53 >= 2*24 + 2)
-__device__ __forceinline__ float unorm8(uint8_t x) { return (float)x / 255.0f; }
-// The correctly rounded quotient a / b from y = RN(1 / b): q = RN(a y) is within an ulp, r = a - b q is exact in one FMA, and
-// RN(q + r y) is RN(a / b) (Markstein's theorem; it needs y correctly rounded, b's significand not all ones, and no overflow,
-// underflow or non-finite value on the way -- the callers' conditions).  Three instructions where the IEEE division sequence
-// has eleven (f32) or fifteen (f64); the explicit FMAs are not contractions (-ffp-contract=off only governs a * b + c).
-// Checked against exact rational arithmetic for every u16 / 60000.0f and u16 / 2000.0 and 600 000 random quotients of the
-// other two kinds; the byte- and word-exhaustive decode tests compare the results with the oracle's divisions.
-__device__ __forceinline__ float quot_rcp(float a, float b, float y) { float q = a * y; return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q); }
-__device__ __forceinline__ double quot_rcp(double a, double b, double y) { double q = a * y; return __builtin_fma(__builtin_fma(-b, q, a), y, q); }
+__device__ __forceinline__ float unorm8(uint8_t x) { return div255((float)x); }
 // UNORM = functor returning x/255 for a byte (direct division, or a 256-entry LDS table)
 template <typename UNORM>
 __device__ __forceinline__ BumpCell decode_cell(uint16_t b0, uint16_t b1, uint16_t b2, uint8_t r, uint8_t g, uint8_t b, uint8_t mk,
@@ -538,8 +561,8 @@ __device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, c
             int si_ = reflect101(ii, n), sj = reflect101(jj, m);
             const uint8_t *px = bgr + (size_t)(n - si_ - 1) * bpitch + 3 * (size_t)sj;
             // (float)((double)x / 255.0) == x / 255.0f: double rounding is innocuous for division (53 >= 2*24+2)
-            float fr = (float)px[2] / 255.0f, fg = (float)px[1] / 255.0f, fb = (float)px[0] / 255.0f;   // Kernel.cu:749-751
-            inten = ((fb + fg) + fr) / 3.0f;                                                           // Kernel.cu:678
+            float fr = div255((float)px[2]), fg = div255((float)px[1]), fb = div255((float)px[0]);       // Kernel.cu:749-751
+            inten = div3_unit((fb + fg) + fr);                                                         // Kernel.cu:678
             if (in_img && r >= 1 && r <= TILE_H && cc >= 1 && cc <= TILE_W) {
                 size_t idx = (size_t)ii * m + jj;
                 st3(RGB, idx, fr, fg, fb);

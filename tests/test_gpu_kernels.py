@@ -535,6 +535,77 @@ def test_preprocess_fused_all_byte_values(ctx, orc, synth):
     ctx.set_calibration_matrix(synth.TUM_CALIB)
 
 
+def _calib_variants(synth, n, m):
+    base = np.asarray(synth.calib_for(n, m), np.float32)
+    out = {}
+    c = base.copy(); c[0] = 333.3; c[1] = 291.7; c[2] = 0.0; c[3] = 17.25
+    out["odd focal lengths, zero centre (reciprocal path)"] = c
+    c = base.copy(); c[0] = np.frombuffer(np.uint32(0x43FFFFFF).tobytes(), np.float32)[0]       # 511.99997: significand all ones
+    out["focal length with an all-ones significand (plain divisions)"] = c
+    c = base.copy(); c[2] = 1e-30
+    out["centre below 2^-60 (plain divisions)"] = c
+    c = base.copy(); c[9] = 1e-20; c[10] = 1.0
+    out["depth scale below 2^-40 (plain divisions)"] = c
+    c = base.copy(); c[1] = 0.0
+    out["zero focal length (plain divisions, infinite results)"] = c
+    return out
+
+
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4])
+def test_calibrations_on_either_side_of_the_reciprocal_path(ctx, orc, synth, which):
+    """The per-pixel quotients by fx, fy and the depth scale come from host-side reciprocals where the calibration allows it
+    (CalibV::fast) and from plain divisions otherwise: preprocessing, merge, model vertex map and seeding against the oracle for
+    calibrations on either side of that switch, bit for bit (infinities and NaN included)."""
+    import ctypes as C
+    n, m = 61, 150
+    name, calib = list(_calib_variants(synth, n, m).items())[which]
+    ctx.set_calibration_matrix(calib)
+    try:
+        rng = np.random.default_rng(40 + which)
+        d, _ = synth.render(np.eye(3), np.zeros(3), n, m, synth.calib_for(n, m))
+        d[rng.random((n, m)) < 0.05] = 0
+        c = rng.integers(0, 256, (n, m, 3)).astype(np.uint8)
+        v = torch.empty(n, m, 3, device="cuda"); nm = torch.empty(n, m, 3, device="cuda"); rgb = torch.empty(n, m, 3, device="cuda")
+        gx = torch.empty(n, m, device="cuda"); gy = torch.empty(n, m, device="cuda")
+        gd, gcol = dev(d), dev(c)
+        assert ctx.lib.rgbdslam_frame_preprocess(ctx._h, C.c_void_p(gd.data_ptr()), C.c_size_t(2 * m), C.c_void_p(gcol.data_ptr()),
+                                                 C.c_size_t(3 * m), C.c_void_p(v.data_ptr()), C.c_void_p(nm.data_ptr()),
+                                                 C.c_void_p(rgb.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_size_t(4 * m),
+                                                 C.c_void_p(gy.data_ptr()), C.c_size_t(4 * m), n, m) == 0
+        ctx.synchronize()
+        with np.errstate(all="ignore"):
+            rv = orc.vertex_map_kinect(d, calib)
+            rn_ = orc.compute_normal(rv)
+        same(host(v), rv)
+        same(host(nm), rn_)
+        same(host(rgb), orc.cpy_char3(c))
+        # seeding, merge (every branch) and the model's vertex map
+        rgbf = orc.cpy_char3(c)
+        out = torch.empty(n, m, 4, device="cuda")
+        ctx.gpu_add_zbuff_off(gd, 2 * m, dev(rgbf), out, n, m)
+        with np.errstate(all="ignore"):
+            ref = orc.add_zbuff_off(d, rgbf, calib)
+        same(host(out), ref)
+        rgbd = ref.copy()
+        w = rgbd[..., 3]
+        w[10:20] *= 1.5; w[20:30] *= 0.5; w[30:40] = 0
+        w[40:50] += rng.normal(0, 1e-5, w[40:50].shape).astype(np.float32)
+        mask = rng.integers(9, 256, (n, m)).astype(np.uint8)
+        mask[::3] = 11; mask[1::9] = 1; mask[2::9] = 255
+        g_rgbd, g_mask = dev(rgbd), dev(mask)
+        ctx.merge_depth_off(g_rgbd, gd, 2 * m, dev(rgbf), g_mask, n, m)
+        with np.errstate(all="ignore"):
+            r_rgbd, r_mask = orc.merge_depth_off(rgbd, d, rgbf, mask, calib)
+        same(host(g_mask), r_mask)
+        same(host(g_rgbd), r_rgbd)
+        vmap = torch.empty(n, m, 3, device="cuda")
+        ctx.vertex_map_gl(vmap, g_rgbd, n, m)
+        with np.errstate(all="ignore"):
+            same(host(vmap), orc.vertex_map_gl(r_rgbd, calib))
+    finally:
+        ctx.set_calibration_matrix(synth.TUM_CALIB)
+
+
 def test_icp_row_bands_and_gathered_solve(ctx, pkg, orc, pair):
     """Row-sharded ICP on one GPU: the two 'ranks' are two band launches.  Each band's 27 sums equal
     the oracle's two-stage reduction restricted to the band's blocks; the rank-ordered total drives

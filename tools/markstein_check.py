@@ -47,3 +47,31 @@ for _ in range(300000):
     if mark(a, b, 53) != rn(a / b, 53): bad += 1
     n += 1
 print("generic a / param mismatches:", bad, "of", n)
+
+# (5) f32, vectorised: x / 255 for every byte, and (fb + fg) + fr over 3 for ALL 256^3 colour triples (the preprocessing tile)
+import numpy as np
+def fma32(a, b, c):
+    """RN32(a * b + c) for float32 arrays: the product is exact in double; the sum is formed in double and the rare values that
+    land on a float32 rounding boundary after the double rounding are redone with exact rationals."""
+    t = a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)
+    out = t.astype(np.float32)
+    bits = t.view(np.uint64) & np.uint64((1 << 29) - 1)
+    tie = np.nonzero(bits == np.uint64(1 << 28))[0]
+    for k in tie:
+        out[k] = np.float32(float(rn(F(float(a[k])) * F(float(b[k])) + F(float(c[k])), 24)))
+    return out
+def mark32(a, b):
+    b = np.float32(b); y = np.float32(1.0) / b
+    q = a * y
+    r = fma32(np.full_like(a, -b), q, a)
+    assert np.array_equal(r.astype(np.float64), a.astype(np.float64) - np.float64(b) * q.astype(np.float64)), "residual not exact"
+    return fma32(r, np.full_like(a, y), q)
+x = np.arange(256, dtype=np.float32)
+u = x / np.float32(255.0)
+print("byte / 255.0f mismatches:", int((mark32(x, 255.0) != u).sum()))
+bad = 0
+for fr in range(256):
+    s = (u[:, None] + u[None, :]).astype(np.float32) + u[fr]            # (fb + fg) + fr, float32 at each step
+    s = s.reshape(-1).astype(np.float32)
+    bad += int((mark32(s, 3.0) != s / np.float32(3.0)).sum())
+print("((fb + fg) + fr) / 3.0f mismatches over 256^3 triples:", bad)
