@@ -46,6 +46,14 @@ int rgbdslam_synchronize(rgbdslam_ctx *ctx);
  * at create; 0 = block at once).  A blocked wait is woken tens of microseconds after the stream drains; the frame is 112 us.
  * No reference counterpart (the reference blocks in cudaDeviceSynchronize after every wrapper). */
 int rgbdslam_set_sync_spin(rgbdslam_ctx *ctx, int microseconds);
+/* Auxiliary ICP records of a frame (no reference counterpart: MatchKernelGaussNewton forms these four values per sample and
+ * iteration, ICP.cu:167-173): f32x4 per pixel = Gx / 8, Gy / 8, (r + g + b) / 3 and the depth weight 0.0012 / (0.0012 +
+ * 0.0019 (z' - 0.4)^2), z' = -VMap.z -- each the reference's expression on the frame's stored maps, so the sums are unchanged.
+ * aux_write (16-byte aligned, n*m*16 bytes, or NULL): the NEXT launch that preprocesses a frame (rgbdslam_frame_preprocess,
+ * ..._model_segment_merge_claim_preprocess, ..._update_apply_tracked_preprocess) leaves that frame's records there.  aux_read
+ * (or NULL): the NEXT rgbdslam_track_frame[_sharded] in persistent-loop mode reads them (one 16-byte gather instead of five
+ * words from three maps, ~60 fewer issue slots per sample); they must belong to the maps passed to that call.  One call each. */
+int rgbdslam_set_frame_aux(rgbdslam_ctx *ctx, float *aux_write, const float *aux_read);
 /* Stores up to RGBDSLAM_COPY_MAX_SEGMENTS device ranges into memory the device can write -- pinned host memory, or device
  * memory -- with ONE launch on the context's stream (no reference counterpart: the reference reads its poses back with blocking
  * cudaMemcpy, RG.cpp:898-903; a hipMemcpyAsync per range is a blit launch each).  Addresses and sizes are multiples of 4

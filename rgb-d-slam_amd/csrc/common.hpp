@@ -49,6 +49,9 @@ struct rgbdslam_ctx {
     int icp_loop;                  // rgbdslam_set_icp_loop
     int icp_line_check;            // rgbdslam_set_icp_line_check
     int icp_timeout_ticks;         // rgbdslam_debug_set_icp_timeout
+    // rgbdslam_set_frame_aux: where the NEXT fused preprocessing launch leaves the frame's auxiliary ICP records, and the records
+    // the NEXT rgbdslam_track_frame reads (each consumed by that call)
+    float *aux_write; const float *track_aux;
     int sync_spin_us;              // rgbdslam_synchronize polls the stream this long before it blocks (rgbdslam_set_sync_spin)
     int seg3_fused;                // rgbdslam_model_segment_merge_claim as one launch (RGBDSLAM_SEG3=0: the three-launch form)
     // instrumentation (rgbdslam_profile_*): HIP-event pairs around every launch of one named kernel
@@ -92,6 +95,13 @@ bool prof_group_begin(rgbdslam_ctx *ctx, const char *kname);
 void prof_group_end(rgbdslam_ctx *ctx);
 // predict.hip: resolves the device address of the static z-buffer of rgbdslam_predict_raster_noalloc on `device`
 int raster_noalloc_setup(int device, unsigned long long **out);
+// ---- D1/ICP.cu:173: weight of a correspondence from the depth component z of the current frame's vertex (shared by the ICP
+// kernels and by the preprocessing that leaves it in the frame's auxiliary records) ----------------------------------------
+__device__ __forceinline__ float icp_depth_weight(float z) {
+    const float sd = -z;
+    return (float)(0.0012 / (0.0012 + 0.0019 * ((double)sd - 0.4) * ((double)sd - 0.4)));
+}
+
 #define KLAUNCH(ctx, kern, grid, block, ...)                                         \
     do {                                                                             \
         bool _prof = (ctx)->prof_name && prof_begin((ctx), #kern);                   \

@@ -23,6 +23,7 @@ extern "C" int rgbdslam_create(rgbdslam_ctx **out, int device, void *stream) {
     for (int k = 0; k < 16; k++) c->pose.v[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->buf_dev = nullptr; c->icp_timing_dev = nullptr; c->outbuf_dev = nullptr; c->out_host = nullptr; c->icp_state = nullptr; c->icp_epoch_dev = nullptr; c->icp_block = nullptr; c->icp_epoch_base = 0; c->icp_loop = 0; c->icp_line_check = 0; c->icp_timeout_ticks = 5000000;
     { const char *e = getenv("RGBDSLAM_SEG3"); c->seg3_fused = !(e && e[0] == '0'); }
+    c->aux_write = nullptr; c->track_aux = nullptr;
     { const char *e = getenv("RGBDSLAM_SYNC_SPIN_US"); c->sync_spin_us = e ? atoi(e) : 5000; if (c->sync_spin_us < 0) c->sync_spin_us = 0; }
     for (int k = 0; k < RGBDSLAM_COMPAT_MAX_PLANES; k++) c->claim_slab[k] = nullptr;
     c->claim_tab_dev = nullptr; c->claim_cells = 0; c->claim_stamp = 0; c->label_swap = nullptr; c->label_swap_px = 0; c->compat_counter = nullptr;
@@ -120,6 +121,17 @@ extern "C" int rgbdslam_synchronize(rgbdslam_ctx *ctx) {
         }
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// The frame's auxiliary ICP records (16 bytes per pixel: the scaled gradients, the intensity and the depth weight the ICP rows
+// take from the current frame, ICP.cu:167-173): aux_write -> the NEXT launch that preprocesses a frame (rgbdslam_frame_preprocess
+// and the launches it rides on) also leaves the records of that frame there; aux_read -> the NEXT rgbdslam_track_frame reads
+// them instead of forming the four values per sample and iteration.  Either may be NULL; each is consumed by that one call.
+extern "C" int rgbdslam_set_frame_aux(rgbdslam_ctx *ctx, float *aux_write, const float *aux_read) {
+    if (!ctx) return RGBDSLAM_E_ARG;
+    if ((((uintptr_t)aux_write | (uintptr_t)aux_read) & 15) != 0) return RGBDSLAM_E_ARG;
+    ctx->aux_write = aux_write; ctx->track_aux = aux_read;
     return 0;
 }
 

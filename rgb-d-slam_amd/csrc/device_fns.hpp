@@ -536,6 +536,7 @@ struct PreprocessArgs {
     float *VMap, *NMap, *RGB, *gx; size_t gx_pitch; float *gy; size_t gy_pitch;
     CalibV c;
     int n, m;
+    float *aux;                                       // optional: the frame's auxiliary ICP records (rgbdslam_set_frame_aux), f32x4 per pixel
 };
 __device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, const int bx, const int by) {
     const uint16_t *__restrict__ depth = a.depth; const size_t dpitch = a.dpitch;
@@ -545,8 +546,10 @@ __device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, c
     const size_t gx_pitch = a.gx_pitch, gy_pitch = a.gy_pitch;
     const CalibV &c = a.c;
     const int n = a.n, m = a.m;
+    float *__restrict__ aux = a.aux;
     __shared__ float sv[HALO_H][HALO_W][3];   // vertices of the tile + halo
     __shared__ float si[HALO_H][HALO_W];      // intensities, halo by reflect-101
+    __shared__ float sic[TILE_H][TILE_W];     // own pixels: the intensity in the ICP's order of additions (ICP.cu:167)
     const int j0 = bx * TILE_W, i0 = by * TILE_H;
     const int tid = threadIdx.y * TILE_W + threadIdx.x;
     for (int e = tid; e < HALO_N; e += TILE_W * TILE_H) {
@@ -567,6 +570,7 @@ __device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, c
                 size_t idx = (size_t)ii * m + jj;
                 st3(RGB, idx, fr, fg, fb);
                 st3(VMap, idx, v.x, v.y, v.z);
+                if (aux) sic[r - 1][cc - 1] = div3_unit((fr + fg) + fb);   // (r + g) + b over 3: the same sums, another order
             }
         }
         si[r][cc] = inten;
@@ -603,9 +607,20 @@ __device__ __forceinline__ void frame_preprocess_tile(const PreprocessArgs &a, c
     float s = 0.0f;
     s = s + rowd[0] * 1.0f; s = s + rowd[1] * 2.0f; s = s + rowd[2] * 1.0f;
     *(float *)((char *)gx + (size_t)i * gx_pitch + 4 * (size_t)j) = s;
+    const float sgx = s;
     s = 0.0f;
     s = s + rows[0] * -1.0f; s = s + rows[1] * 0.0f; s = s + rows[2] * 1.0f;
     *(float *)((char *)gy + (size_t)i * gy_pitch + 4 * (size_t)j) = s;
+    if (aux) {
+        // what MatchKernelGaussNewton takes from this pixel when a model point projects onto it (ICP.cu:167-173), formed once
+        // here from the values just stored: gradients / 8 (in double, as there), intensity, depth weight
+        float4 x;
+        x.x = (float)((double)sgx / 8.0);
+        x.y = (float)((double)s / 8.0);
+        x.z = sic[threadIdx.y][threadIdx.x];
+        x.w = icp_depth_weight(p.z);
+        *(float4 *)(aux + 4 * idx) = x;
+    }
 }
 
 // ---- D1/Primitive.cu:267-357 UpdateKernel under the winner rule: one tile ---------------------------

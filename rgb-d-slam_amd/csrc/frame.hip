@@ -678,7 +678,8 @@ extern "C" int rgbdslam_frame_preprocess(rgbdslam_ctx *ctx, const uint16_t *dept
     if (depth_pitch < 2 * (size_t)m || bgr_pitch < 3 * (size_t)m || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m)
         return RGBDSLAM_E_ARG;
     if (!ctx->have_calib) return RGBDSLAM_E_STATE;
-    PreprocessArgs a = {depth, depth_pitch, bgr, bgr_pitch, VMap, NMap, RGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    PreprocessArgs a = {depth, depth_pitch, bgr, bgr_pitch, VMap, NMap, RGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m, ctx->aux_write};
+    ctx->aux_write = nullptr;                         // announced for one launch (rgbdslam_set_frame_aux)
     KLAUNCH(ctx, k_frame_preprocess, grid2d(n, m), block2d(), a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -923,7 +924,8 @@ extern "C" int rgbdslam_model_segment_merge_claim_preprocess(
     if (next_depth_pitch < 2 * (size_t)m || next_bgr_pitch < 3 * (size_t)m || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m)
         return RGBDSLAM_E_ARG;
     if (fRGB == RGB || fVMap == VMap_pred || fVMap == VMap_out || fNMap == NMap_out || fNMap == NMap_seg) return RGBDSLAM_E_ARG;
-    PreprocessArgs pp = {next_depth, next_depth_pitch, next_bgr, next_bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    PreprocessArgs pp = {next_depth, next_depth_pitch, next_bgr, next_bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m, ctx->aux_write};
+    ctx->aux_write = nullptr;                         // announced for one launch (rgbdslam_set_frame_aux)
     if (labels16(ctx))
         return segment_merge_claim_impl(ctx, pose_block_dev, NMap_seg, VMap_pred, (uint16_t *)Label, (uint16_t *)Label_swap, Equations_dev,
                                         nbPlans, epsilon, alpha, RGBD_in, Mask_in, depth, depth_pitch, RGB, RGBD_out, Mask_out, VMap_out,

@@ -249,7 +249,8 @@ extern "C" int rgbdslam_update_apply_tracked_preprocess(rgbdslam_ctx *ctx, const
     const bool l16 = labels16(ctx);
     UpdateArgs u = {BumpTab, RGBTab, MaskTab, ParamTab, (unsigned long long *const *)ClaimTab, stamp, VMap, RGBD, Mask, l16 ? nullptr : Label,
                     l16 ? (const uint16_t *)Label : nullptr, P, pb, nullptr, N_prim, M_prim, n, m, plane_lo, plane_hi};
-    PreprocessArgs p = {next_depth, depth_pitch, next_bgr, bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m};
+    PreprocessArgs p = {next_depth, depth_pitch, next_bgr, bgr_pitch, fVMap, fNMap, fRGB, gx, gx_pitch, gy, gy_pitch, ctx->calib, n, m, ctx->aux_write};
+    ctx->aux_write = nullptr;                         // announced for one launch (rgbdslam_set_frame_aux)
     dim3 grid = grid2d(n, m);
     const int gy_update = (int)grid.y;
     grid.y *= 2;

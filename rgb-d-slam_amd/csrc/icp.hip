@@ -25,7 +25,11 @@ struct IcpRow { float g[7]; float c[7]; };
 // trips; the arithmetic and its order are untouched).
 struct IcpModelRaw { F3 np, vp; float cx, cy, cz; };   // a model sample as loaded
 struct IcpModelPx { F3 np, vp; float ip; };   // ip = intensity of the model pixel (ICP.cu:100), the only use of its colour
-struct IcpCurrPx { F3 nc, s, cc; float gx, gy; };
+// what the rows need of the current frame at the projected pixel: normal, vertex, and four values that are functions of that
+// pixel alone -- the scaled gradients g0, g1 (ICP.cu:168-169), the intensity ic (ICP.cu:167) and the depth weight w
+// (ICP.cu:173) -- either formed here from the gathered colour / gradients / vertex, or read ready-made from the frame's
+// auxiliary record (icp_gather_aux)
+struct IcpCurrPx { F3 nc, s; float g0, g1, ic, w; };
 struct IcpProj { float d0, d1, d2, n0, n1, n2, az; int pu, pv; unsigned int pidx; };   // pidx < 2^28: launch_iter checks the image size
 
 __device__ __forceinline__ IcpModelPx icp_load_model(size_t indx, const float *__restrict__ VMap_prev,
@@ -70,6 +74,9 @@ __device__ __forceinline__ IcpProj icp_project(const IcpModelPx &mp, const float
     p.pidx = (unsigned int)p.pv * (unsigned int)m + (unsigned int)p.pu;
     return p;
 }
+// The consumers of the gathered values sit behind early exits (zero normal, distance, angle); left alone, the
+// compiler sinks each load behind the exit that precedes its first use and the gather becomes three dependent
+// memory round trips.  Passing the values through an empty asm pins all the loads before the first test.
 __device__ __forceinline__ IcpCurrPx icp_gather(const IcpProj &p, const float *__restrict__ VMap, const float *__restrict__ NMap,
                                                 const float *__restrict__ RGB, const float *__restrict__ Gx, size_t gxp,
                                                 const float *__restrict__ Gy, size_t gyp) {
@@ -78,25 +85,32 @@ __device__ __forceinline__ IcpCurrPx icp_gather(const IcpProj &p, const float *_
     const unsigned int o12 = 12u * p.pidx;
     c.nc = *(const F3 *)((const char *)NMap + o12);
     c.s = *(const F3 *)((const char *)VMap + o12);
-    c.cc = *(const F3 *)((const char *)RGB + o12);
-    c.gx = *(const float *)((const char *)Gx + ((unsigned int)p.pv * (unsigned int)gxp + 4u * (unsigned int)p.pu));
-    c.gy = *(const float *)((const char *)Gy + ((unsigned int)p.pv * (unsigned int)gyp + 4u * (unsigned int)p.pu));
+    F3 cc = *(const F3 *)((const char *)RGB + o12);
+    float gx = *(const float *)((const char *)Gx + ((unsigned int)p.pv * (unsigned int)gxp + 4u * (unsigned int)p.pu));
+    float gy = *(const float *)((const char *)Gy + ((unsigned int)p.pv * (unsigned int)gyp + 4u * (unsigned int)p.pu));
+    asm volatile("" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(cc.x), "+v"(cc.y),
+                 "+v"(cc.z), "+v"(gx), "+v"(gy));
+    c.ic = ((cc.x + cc.y) + cc.z) / 3.0f;
+    c.g0 = (float)((double)gx / 8.0);
+    c.g1 = (float)((double)gy / 8.0);
+    c.w = icp_depth_weight(c.s.z);
     return c;
 }
-
-// The consumers of the gathered values sit behind early exits (zero normal, distance, angle); left alone, the
-// compiler sinks each load behind the exit that precedes its first use and the gather becomes three dependent
-// memory round trips.  Passing the values through an empty asm pins all five loads before the first test.
-__device__ __forceinline__ void icp_pin_gather(IcpCurrPx &c) {
-    asm volatile("" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(c.cc.x), "+v"(c.cc.y),
-                 "+v"(c.cc.z), "+v"(c.gx), "+v"(c.gy));
-}
-
-// the same pin on the path that has just requested the next level's samples (a distinct statement on purpose: merged with
-// the other one behind the join, the wait would have to cover the requests only one path has made -- all of them)
-__device__ __forceinline__ void icp_pin_gather_after_prefetch(IcpCurrPx &c) {
-    asm volatile("; gather before prefetch" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(c.cc.x),
-                 "+v"(c.cc.y), "+v"(c.cc.z), "+v"(c.gx), "+v"(c.gy));
+// The same from the frame's auxiliary records (16 bytes per pixel: g0, g1, ic, w as the fused preprocessing left them,
+// rgbdslam_set_frame_aux): one 16-byte load instead of five words from three maps, and the division, the two conversions and
+// the f64 quotient of w (~60 issue slots of a ~500-slot block) are paid once per pixel and frame by the preprocessing instead
+// of once per sample and iteration here.  The values are formed by the same expressions from the same stored maps.
+__device__ __forceinline__ IcpCurrPx icp_gather_aux(const IcpProj &p, const float *__restrict__ VMap, const float *__restrict__ NMap,
+                                                    const float *__restrict__ Aux) {
+    IcpCurrPx c;
+    const unsigned int o12 = 12u * p.pidx;
+    c.nc = *(const F3 *)((const char *)NMap + o12);
+    c.s = *(const F3 *)((const char *)VMap + o12);
+    float4 x = *(const float4 *)((const char *)Aux + 16u * p.pidx);
+    asm volatile("; aux gather" : "+v"(c.nc.x), "+v"(c.nc.y), "+v"(c.nc.z), "+v"(c.s.x), "+v"(c.s.y), "+v"(c.s.z), "+v"(x.x), "+v"(x.y),
+                 "+v"(x.z), "+v"(x.w));
+    c.g0 = x.x; c.g1 = x.y; c.ic = x.z; c.w = x.w;
+    return c;
 }
 
 // Returns false -> o untouched (the caller passes zeroed rows and needs no copy).  The four rejection tests of
@@ -124,17 +138,13 @@ __device__ __forceinline__ bool icp_rows(const IcpModelPx &mp, const IcpProj &pr
     const bool reject = (int)!inside | (int)is_zero3(mp.np) | (int)is_zero3(nc) | (int)(dist2 > distThres) | (int)(ang2 > angleThres);
     if (reject) return false;
 
-    F3 cc = cu.cc;
-    float i_curr = ((cc.x + cc.y) + cc.z) / 3.0f;
-    float g0 = (float)((double)cu.gx / 8.0);
-    float g1 = (float)((double)cu.gy / 8.0);
-    float g2 = i_curr - i_prev;
+    const float g0 = cu.g0, g1 = cu.g1;
+    float g2 = cu.ic - i_prev;
     proj = (int)pidx;
 
     // ---- rows (D1/ICP.cu:175-205).  Products with the literal 0/1 entries of JD/JRot are
     // dropped: they are exact for finite inputs, so the remaining operations round identically.
-    float sd = -s.z;
-    float w = (float)(0.0012 / (0.0012 + 0.0019 * ((double)sd - 0.4) * ((double)sd - 0.4)));
+    const float w = cu.w;
     float e0 = s.x - d0, e1 = s.y - d1, e2 = s.z - d2;
     float tdx = 2.0f * d0, tdy = 2.0f * d1, tdz = 2.0f * d2;
     float tnx = 2.0f * n0, tny = 2.0f * n1, tnz = 2.0f * n2;
@@ -281,6 +291,7 @@ struct IcpIterArgs {
     const float *intr, *R, *t;                       // device scalars (user buffers or &IcpState fields)
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
     size_t gxp, gyp;
+    const float *Aux;                                // optional: the frame's auxiliary records (icp_gather_aux), else NULL
     const float *VMap_prev, *NMap_prev, *RGBD_prev;
     float distThres, angleThres;                     // icp_sq_threshold(distThres), icp_sq_threshold(angleThres): see icp_rows
     int n, m, fact;
@@ -535,8 +546,9 @@ __device__ __forceinline__ void icp_iter_body(const IcpIterArgs &a, const IcpSha
             for (int z = 0; z < 7; z++) { q.g[z] = 0.0f; q.c[z] = 0.0f; }
             if (LOOP && r == 0 && want_next && t == nwg - 1) request_next();   // the tail: see below
             IcpProj pr = icp_project(mp, Rc, tc3, in4, a.n, a.m);
-            IcpCurrPx cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
-            icp_pin_gather(cu);
+            IcpCurrPx cu;
+            if (a.Aux) cu = icp_gather_aux(pr, a.VMap, a.NMap, a.Aux);      // (uniform)
+            else cu = icp_gather(pr, a.VMap, a.NMap, a.RGB, a.Gx, a.gxp, a.Gy, a.gyp);
             int proj = -1;
             const bool ok = icp_rows(mp, pr, cu, in4, a.distThres, a.angleThres, inside, q, proj);
             if (!LOOP && a.corr && inside) a.corr[idx] = ok ? proj : -1;
@@ -775,6 +787,7 @@ static_assert(ICP_OFF_PUB % 128 == 0 && offsetof(IcpState, tcurr) == 21 * 4, "pu
 static_assert(sizeof(IcpState) <= 128, "state slot");
 struct IcpLoopArgs {
     const float *VMap, *NMap, *RGB, *Gx, *Gy, *VMap_prev, *NMap_prev, *RGBD_prev;
+    const float *Aux;                                // the frame's auxiliary records or NULL (icp_gather_aux)
     unsigned int gxp, gyp;
     char *block;                                     // the ICP work block (offsets above)
     rgbdslam_pose_block *pb;
@@ -836,7 +849,7 @@ void k_icp_loop(IcpLoopArgs L) {
             a.line_check = CHECK; a.rejections = (unsigned int *)(L.block + ICP_OFF_EPOCH) + ICP_OFF_REJECT_WORD;
             a.timeout_ticks = L.timeout_ticks;
             a.intr = nullptr; a.R = nullptr; a.t = nullptr;
-            a.VMap = L.VMap; a.NMap = L.NMap; a.RGB = L.RGB; a.Gx = L.Gx; a.Gy = L.Gy; a.gxp = L.gxp; a.gyp = L.gyp;
+            a.VMap = L.VMap; a.NMap = L.NMap; a.RGB = L.RGB; a.Gx = L.Gx; a.Gy = L.Gy; a.gxp = L.gxp; a.gyp = L.gyp; a.Aux = L.Aux;
             a.VMap_prev = L.VMap_prev; a.NMap_prev = L.NMap_prev; a.RGBD_prev = L.RGBD_prev;
             a.distThres = L.distThres; a.angleThres = L.angleThres;
             a.n = L.n; a.m = L.m;
@@ -1580,7 +1593,7 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.line_check = ctx->icp_line_check; a.rejections = ctx->icp_epoch_dev ? ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD : nullptr;
     a.timeout_ticks = ctx->icp_timeout_ticks;
     a.intr = intr; a.R = R; a.t = t;
-    a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
+    a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp; a.Aux = nullptr;
     a.VMap_prev = mp.VMap_prev; a.NMap_prev = mp.NMap_prev; a.RGBD_prev = mp.RGB_prev;
     a.distThres = icp_sq_threshold(distThres); a.angleThres = icp_sq_threshold(angleThres);
     a.n = n; a.m = m; a.fact = fact; a.grid_rows = gr; a.grid_cols = gc;
@@ -1645,6 +1658,8 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
     if (!ctx || !prm || !VMap || !NMap || !RGB || !Gx || !Gy || !VMap_prev || !NMap_prev || !RGB_prev ||
         !pose_state_dev || !status_dev)
         return RGBDSLAM_E_ARG;
+    const float *aux = ctx->track_aux;                         // announced for this call only (rgbdslam_set_frame_aux)
+    ctx->track_aux = nullptr;
     int rc = check_align_args(ctx, prm, n, m, gxp, gyp);
     if (rc) return rc;
     IcpState *st = ctx->icp_state;
@@ -1679,6 +1694,8 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
         for (int k = nl; k < 3; k++) { L.lv[k] = L.lv[0]; L.lv[k].w0 |= ICP_LV_UNUSED; }
         if (!icp_offsets_fit(n, m, gxp, gyp)) return RGBDSLAM_E_ARG;
         L.VMap = VMap; L.NMap = NMap; L.RGB = RGB; L.Gx = Gx; L.Gy = Gy; L.gxp = (unsigned int)gxp; L.gyp = (unsigned int)gyp;
+        // the frame's auxiliary records, if the caller announced them for THIS call (rgbdslam_set_frame_aux; 32-bit byte offsets)
+        L.Aux = (size_t)n * m * 16 <= 0xffffffffull ? aux : nullptr;
         L.VMap_prev = VMap_prev; L.NMap_prev = NMap_prev; L.RGBD_prev = RGB_prev;
         L.block = ctx->icp_block; L.pb = pose_block; L.history = history; L.frame_index = frame_index;
         L.distThres = icp_sq_threshold(prm->distThres); L.angleThres = icp_sq_threshold(prm->angleThres);

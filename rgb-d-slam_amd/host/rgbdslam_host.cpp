@@ -330,6 +330,14 @@ void OffLineFrame::PrepareOtherSet() {
     if (!_Gx[o].p) { _Gx[o].alloc(P); _Gy[o].alloc(P); }
 }
 
+void OffLineFrame::announce_aux(bool other) {
+    const int set = _cur ^ (other ? 1 : 0);
+    if (!_aux_enabled) { _aux_valid[set] = false; return; }
+    if (!_Aux[set].p) _Aux[set].alloc(4 * (size_t)_n * _m);
+    check(rgbdslam_set_frame_aux(_ctx, _Aux[set].p, nullptr), "set_frame_aux");
+    _aux_valid[set] = true;
+}
+
 void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
     // kernels are enqueued on the context's stream: point it at the load stream for the duration of the load
     hipStream_t main = ctx_stream(_ctx);
@@ -343,9 +351,11 @@ void OffLineFrame::preprocess(const uint8_t *bgr, size_t bgr_pitch) {
         _depth_pitch[_cur] = 2 * (size_t)_m;
     }
     if (_gradients) {
+        announce_aux(false);
         rc = rgbdslam_frame_preprocess(_ctx, _depth_cur[_cur], _depth_pitch[_cur], bgr, bgr_pitch, getVMap(), getNMap(), getRGB(), getGx(),
                                        4 * (size_t)_m, getGy(), 4 * (size_t)_m, _n, _m);
     } else {
+        _aux_valid[_cur] = false;
         rc = rgbdslam_gpu_cpy_char3(_ctx, bgr, bgr_pitch, getRGB(), _n, _m);                                  // Frame.cpp:65
         if (!rc) rc = rgbdslam_vertex_map_kinect(_ctx, getVMap(), _depth_cur[_cur], _depth_pitch[_cur], _n, _m);   // :68
         if (!rc) rc = rgbdslam_compute_normal(_ctx, getNMap(), getVMap(), _n, _m, 1);                         // :71
@@ -480,6 +490,7 @@ void PredictedFrame::SegmentMergeClaimFused(const rgbdslam_pose_block *pb, float
     if (next_depth) {
         frame->PrepareOtherSet();
         const size_t gp = 4 * (size_t)_m;
+        frame->announce_aux(true);
         check(rgbdslam_model_segment_merge_claim_preprocess(
                   _ctx, pb, _NMap_seg.p, _VMap_alt.p, _Label_dev_swap, _Label_dev, Equations_dev, nbPlans, 0.1f, 0.9f, _RGB_alt.p,
                   _Mask_dev_swap, frame->depth(), frame->depth_pitch(), frame->getRGB(), _RGB_dev.p, _Mask_dev, _VMap_dev.p, _NMap_dev.p,
@@ -633,6 +644,7 @@ void Graph::ApplyTracked(PredictedFrame *frame, const rgbdslam_pose_block *pb, c
 void Graph::ApplyTrackedAndPreprocess(PredictedFrame *frame, const rgbdslam_pose_block *pb, const UpdateTables &t, OffLineFrame *next,
                                       const uint16_t *depth_dev, size_t depth_pitch, const uint8_t *bgr_dev, size_t bgr_pitch) {
     const size_t gp = 4 * (size_t)frame->_m;
+    next->announce_aux(false);
     check(rgbdslam_update_apply_tracked_preprocess(_ctx, pb, t.Bump, t.RGB, t.Mask, t.Param, t.Claim, t.stamp, frame->getVMap(),
                                                    frame->getRGB(), frame->_Mask_dev, frame->_Label_dev, t.N_prim, t.M_prim, frame->_n,
                                                    frame->_m, t.plane_lo, t.plane_hi, depth_dev, depth_pitch, bgr_dev, bgr_pitch,
@@ -1346,6 +1358,7 @@ int RG::StepAsync() {
     const int slot = frames_done % HISTORY_CAP;
     stage_mark(2);
     { StageRange r("stage 2+3: ICP + 27-term reduction (RG::AlignFrameGaussNewton)");
+    if (_frame->getAux()) check(rgbdslam_set_frame_aux(_ctx, nullptr, _frame->getAux()), "set_frame_aux");   // this call's records
     check(rgbdslam_track_frame(_ctx, &prm, _frame->getVMap(), _frame->getNMap(), _frame->getRGB(), _frame->getGx(), pitch, _frame->getGy(), pitch,
                                _predicted_frame->getVMap(), _predicted_frame->getNMap(), _predicted_frame->getRGB(), n, m, _pb_dev,
                                _history_dev.p, slot), "track_frame");               // GP-demo.cpp:189 + 201-245

@@ -127,6 +127,12 @@ public:
     bool has_gradients() const { return _gradients; }
     float *getGx() { return _Gx[_cur].p; }
     float *getGy() { return _Gy[_cur].p; }
+    // Auxiliary ICP records of a buffer set (rgbdslam_set_frame_aux: gradients / 8, intensity, depth weight per pixel, written by
+    // the fused preprocessing next to the maps, read by the persistent ICP kernel).  announce_aux: call right before the launch
+    // that preprocesses into the current (other = false) or the other buffer set; getAux: the current set's records, or NULL when
+    // its maps were not produced that way.  RGBDSLAM_NO_AUX=1 switches the records off (A/B).
+    void announce_aux(bool other);
+    const float *getAux() const { return _aux_valid[_cur] ? _Aux[_cur].p : nullptr; }
     const uint16_t *depth() const { return _depth_cur[_cur]; }
     size_t depth_pitch() const { return _depth_pitch[_cur]; }
     // Overlap: loads go to `load_stream` and alternate between the two buffer sets.  wait_ready(consumer) = the current
@@ -143,7 +149,9 @@ private:
     void preprocess(const uint8_t *bgr, size_t bgr_pitch);
     DevBuf<uint16_t> _depth_dev_test[2];
     DevBuf<uint8_t> _color_dev_test[2];
-    DevBuf<float> _Gx[2], _Gy[2];
+    DevBuf<float> _Gx[2], _Gy[2], _Aux[2];
+    bool _aux_valid[2] = {false, false};
+    bool _aux_enabled = getenv("RGBDSLAM_NO_AUX") == nullptr;
     const uint16_t *_depth_cur[2] = {nullptr, nullptr};
     size_t _depth_pitch[2] = {0, 0};
     bool _gradients = false, _bilateral = false;

@@ -943,6 +943,87 @@ def test_icp_1080p_four_bands_and_persistent_loop(ctx, pkg, orc, synth):
     same(out[1][9:12], t)
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (61, 150)])
+def test_frame_aux_records(ctx, pkg, orc, synth, shape):
+    """rgbdslam_set_frame_aux: (a) the records the fused preprocessing leaves are the reference's four per-pixel expressions
+    (ICP.cu:167-173) on the stored maps, bit for bit -- Gx / 8 and Gy / 8 in double, (r + g + b) / 3, the depth weight in double;
+    (b) an announcement holds for ONE launch: the next preprocessing without one writes nothing; (c) the persistent ICP
+    kernel fed with the records leaves the pose block of the run without them and of the multi-launch path, word for word,
+    and the oracle's pose; (d) an announcement for track_frame is consumed by it."""
+    import ctypes as C
+    n, m = shape
+    lib = ctx.lib
+    calib = synth.calib_for(n, m)
+    ctx.set_calibration_matrix(calib)
+    ctx.alloc_buffers(60, 80)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    try:
+        rng = np.random.default_rng(12)
+        R1, t1 = synth.pair_offset_pose()
+        maps = []
+        for k, (R, t) in enumerate(((np.eye(3), np.zeros(3)), (R1, t1))):
+            d, c = synth.render(R, t, n, m, calib)
+            d[rng.random((n, m)) < 0.02] = 0
+            c = c.copy(); c.reshape(-1)[:256] = np.arange(256)                      # every byte value
+            v, nm, rgb = (torch.empty(n, m, 3, device="cuda") for _ in range(3))
+            gx, gy = torch.empty(n, m, device="cuda"), torch.empty(n, m, device="cuda")
+            aux = torch.full((n, m, 4), -7.0, device="cuda")
+            gd, gc = dev(d), dev(c)
+            call = lambda: lib.rgbdslam_frame_preprocess(ctx._h, p(gd), C.c_size_t(2 * m), p(gc), C.c_size_t(3 * m), p(v), p(nm), p(rgb),
+                                                         p(gx), C.c_size_t(4 * m), p(gy), C.c_size_t(4 * m), n, m)
+            assert lib.rgbdslam_set_frame_aux(ctx._h, p(aux), None) == 0
+            assert call() == 0
+            ctx.synchronize()
+            rv = orc.vertex_map_kinect(d, calib); rrgb = orc.cpy_char3(c)
+            _, rgx, rgy = orc.intensity_sobel(rrgb)
+            same(host(v), rv); same(host(gx), rgx); same(host(gy), rgy); same(host(rgb), rrgb)
+            want = np.empty((n, m, 4), np.float32)
+            want[..., 0] = (rgx.astype(np.float64) / 8.0).astype(np.float32)
+            want[..., 1] = (rgy.astype(np.float64) / 8.0).astype(np.float32)
+            want[..., 2] = ((rrgb[..., 0] + rrgb[..., 1]) + rrgb[..., 2]) / np.float32(3.0)
+            sd = (-rv[..., 2]).astype(np.float64)
+            want[..., 3] = (0.0012 / (0.0012 + 0.0019 * (sd - 0.4) * (sd - 0.4))).astype(np.float32)
+            same(host(aux), want)
+            keep = aux.clone()
+            aux.fill_(-7.0)
+            assert call() == 0                                                      # (b) not announced again: nothing written
+            ctx.synchronize()
+            assert (host(aux) == -7.0).all()
+            maps.append(dict(v=v, n=nm, rgb=rgb, gx=gx, gy=gy, aux=keep, hv=rv, hn=orc.compute_normal(rv), hrgb=rrgb))
+        # model = frame 0 as the seeded model (VMap, NMap, RGBD with .w), current = frame 1
+        f0, f1 = maps
+        rgbd0 = np.concatenate([f0["hrgb"], np.zeros((n, m, 1), np.float32)], axis=2)
+        g_rgbd0 = dev(rgbd0)
+        prm = pkg.icp_params()
+        I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
+        out = {}
+        for name, loop, use_aux in (("iter", False, False), ("loop", True, False), ("loop+aux", True, True), ("loop after", True, False)):
+            ctx.set_icp_loop(loop)
+            pb = _pose_block(torch, I, z)
+            hist = torch.zeros(2, 16, device="cuda")
+            if use_aux:
+                assert lib.rgbdslam_set_frame_aux(ctx._h, None, p(f1["aux"])) == 0
+            elif name == "loop after":
+                f1["aux"].fill_(float("nan"))                                        # (d) were it still announced, the pose would be NaN
+            ctx.track_frame(prm, f1["v"], f1["n"], f1["rgb"], f1["gx"], f1["gy"], f0["v"], f0["n"], g_rgbd0, n, m, pb, hist, 0)
+            ctx.synchronize()
+            assert ctx.icp_loop_faults() == 0
+            out[name] = host(pb).copy().view(np.int32)
+        ctx.set_icp_loop(False)
+        for name in ("loop", "loop+aux", "loop after"):
+            same(out[name], out["iter"])
+        ok, R, t, tr = orc.align_gauss_newton(orc.icp_params(), calib[:4], f1["hv"], f1["hn"], f1["hrgb"], f0["hv"], f0["hn"], rgbd0,
+                                              I, z, I, z)
+        assert out["loop+aux"][24] == int(ok) and out["loop+aux"][25] == len(tr)
+        if ok:
+            same(out["loop+aux"][:12].view(np.float32), np.concatenate([R, t]).astype(np.float32))
+        # misaligned records are refused
+        assert lib.rgbdslam_set_frame_aux(ctx._h, C.c_void_p(f1["aux"].data_ptr() + 4), None) == 1
+    finally:
+        ctx.set_icp_loop(False)
+        ctx.set_calibration_matrix(synth.TUM_CALIB)
+
+
 def test_decode_and_mesh_256_planes_full_size(ctx, orc):
     """BASELINE configs[2] at its full size: 256 planes x 512x512 Bump cells, all byte values in the masks.
     Size-independent properties: (a) eight plane ranges (the 8-GPU partition) reproduce the single launch bit for
