@@ -195,6 +195,17 @@ extern "C" int rgbdslam_set_calibration_matrix(rgbdslam_ctx *ctx, const float *c
     auto centre_ok = [](float x) { return x == 0.0f || (fabsf(x) >= 0x1p-60f && fabsf(x) <= 0x1p20f); };
     c.fast = focal_ok(c.v[0]) && focal_ok(c.v[1]) && centre_ok(c.v[2]) && centre_ok(c.v[3]) &&
              (c.s == 0.0f || (fabsf(c.s) >= 0x1p-40f && fabsf(c.s) <= 0x1p40f));
+    // Markstein's theorem wants q = RN(a y) within an ulp of a / b, which holds for most but not all (a, b).  The numerators of
+    // these two quotients are (k - centre) for a pixel index k < 65536 -- a finite set once the calibration is known -- so the
+    // claim is simply checked for every one of them here, with the FMA sequence the kernels use against the division; a
+    // calibration with a single differing quotient keeps the divisions.  (~0.3 ms, once per calibration.)
+    for (int axis = 0; axis < 2 && c.fast; axis++) {
+        const float f = c.v[axis], ctr = c.v[2 + axis], y = axis ? c.inv_fy : c.inv_fx;
+        for (int k = 0; k < 65536; k++) {
+            const float a = (float)k - ctr, q = a * y;
+            if (fmaf(fmaf(-f, q, a), y, q) != a / f) { c.fast = 0; break; }
+        }
+    }
     ctx->have_calib = true;
     return 0;
 }

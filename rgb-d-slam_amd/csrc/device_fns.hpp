@@ -4,12 +4,18 @@
 #pragma once
 #include "common.hpp"
 
-// The correctly rounded quotient a / b from y = RN(1 / b): q = RN(a y) is within an ulp, r = a - b q is exact in one FMA, and
-// RN(q + r y) is RN(a / b) (Markstein's theorem; it needs y correctly rounded, b's significand not all ones, and no overflow,
-// underflow or non-finite value on the way -- the callers' conditions).  Three instructions where the IEEE division sequence
-// has eleven (f32) or fifteen (f64); the explicit FMAs are not contractions (-ffp-contract=off only governs a * b + c).
-// Checked against exact rational arithmetic for every u16 / 60000.0f and u16 / 2000.0 and 600 000 random quotients of the
-// other two kinds; the byte- and word-exhaustive decode tests compare the results with the oracle's divisions.
+// The correctly rounded quotient a / b from y = RN(1 / b): q = RN(a y), r = a - b q in one FMA, RN(q + r y).  Where r is exact
+// (q close enough to a / b for a - b q to fit the format) the last step rounds a / b (1 + e), |e| ~ 2^-2p, i.e. a / b itself
+// unless a / b sits that close to a rounding boundary (Markstein).  That is NOT true of every pair of floats -- about one random
+// f32 pair in 700 has an inexact residual, and divisors whose significand is nearly all ones always do -- so every use below
+// is one of: (a) a constant divisor with a bounded numerator set, checked for EVERY numerator (u16 / 60000, byte / 255, the
+// 256^3 colour sums / 3, all 2^23 significands / 100: tools/markstein_check.py, exact rational arithmetic); (b) an f64
+// quotient whose operands come from floats or small constants (decode_cell), where b q needs at most ~80 bits, the residual
+// always fits and no quotient of such operands can lie within 2^-100 of a boundary; (c) the two calibration quotients, whose
+// 65 536 possible numerators are checked on the host against the division when the calibration is set (context.hip).
+// Three instructions where the IEEE division sequence has eleven (f32) or fifteen (f64); the explicit FMAs are not
+// contractions (-ffp-contract=off only governs a * b + c).  No overflow, underflow or non-finite value may occur on the way:
+// the callers' range conditions.
 __device__ __forceinline__ float quot_rcp(float a, float b, float y) { float q = a * y; return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q); }
 __device__ __forceinline__ double quot_rcp(double a, double b, double y) { double q = a * y; return __builtin_fma(__builtin_fma(-b, q, a), y, q); }
 // x / 255.0f for a byte and x / 3.0f for a sum of three such quotients (0 or in [1/255, 3]): constant denominators, bounded

@@ -75,3 +75,11 @@ for fr in range(256):
     s = s.reshape(-1).astype(np.float32)
     bad += int((mark32(s, 3.0) != s / np.float32(3.0)).sum())
 print("((fb + fg) + fr) / 3.0f mismatches over 256^3 triples:", bad)
+
+# (6) f32, x / 100.0f (depth_over_max) for EVERY significand: the sequence is invariant under scaling by powers of two while
+# nothing overflows or underflows, so the 2^23 floats of [1, 2) stand for every normal numerator
+bad = 0
+for lo in range(0, 1 << 23, 1 << 20):
+    a = (np.arange(lo, lo + (1 << 20), dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+    bad += int((mark32(a, 100.0) != (a.astype(np.float64) / 100.0).astype(np.float32)).sum())
+print("x / 100.0f mismatches over all 2^23 significands (residual exact in every case):", bad)
