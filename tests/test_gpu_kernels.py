@@ -691,6 +691,9 @@ def _solve_cases():
     A = (J.T @ J).astype(np.float32); A = np.triu(A) + np.triu(A, 1).T
     cases.append(("rank deficient", A, b))
     cases.append(("nan right-hand side", d(2, 2, 2, 2, 2, 2), np.asarray([0, 0, np.nan, 0, 0, 0], np.float32)))
+    # tiny and denormal positive pivots with a determinant that passes
+    cases.append(("pivot below 2^-96, determinant 1", d(1e-30, 1e30, 1, 1, 1, 1), b * np.float32(1e-30)))
+    cases.append(("denormal pivot", d(1e-40, 1e20, 1e20, 1, 1, 1), b * np.float32(1e-42)))
     return cases
 
 
@@ -743,7 +746,7 @@ def test_icp_solve_step_on_crafted_systems(ctx, pkg, orc, pair):
                 R = np.linalg.inv(Rinc)
                 assert np.abs(s[:9].reshape(3, 3).T - R).max() <= 1e-5, name
                 assert np.abs(s[9:12] + R @ x_ref[:3].astype(np.float64)).max() <= 1e-5, name
-    assert accepted >= 24 and rejected >= 9, (accepted, rejected)
+    assert accepted >= 25 and rejected >= 9, (accepted, rejected)
 
     # a failed step after an accepted one: the count stays at one, the frame is lost, the pose untouched
     name, A, b = _solve_cases()[0]
