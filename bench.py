@@ -599,6 +599,8 @@ def run_rows(args, env):
         ctx.gpu_add_zbuff_off(g["d0"], 2 * m, g["rgb0"], rgbd0, n, m)
         gx = torch.empty(n, m, device="cuda"); gy = torch.empty(n, m, device="cuda")
         ctx.intensity_sobel(g["rgb1"], None, gx, gy, n, m)
+        aux = torch.empty(n, m, 4, device="cuda")        # the frame's auxiliary ICP records (the persistent form reads them)
+        ctx.frame_aux(g["v1"], g["rgb1"], gx, gy, aux, n, m)
         ctx.alloc_buffers((n + 7) // 8, (m + 7) // 8)
         prm = pkg.icp_params()
         aligner = multigpu.ShardedAligner(ctx, prm, n, m, rank, world, exchange=args.exchange)
@@ -618,7 +620,7 @@ def run_rows(args, env):
 
         def step():
             state.copy_(start)
-            aligner.align(g["v1"], g["n1"], g["rgb1"], gx, gy, g["v0"], g["n0"], rgbd0, state, status)
+            aligner.align(g["v1"], g["n1"], g["rgb1"], gx, gy, g["v0"], g["n0"], rgbd0, state, status, aux=aux)
 
         for _ in range(1 + args.warmup):
             step()

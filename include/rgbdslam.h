@@ -54,6 +54,9 @@ int rgbdslam_set_sync_spin(rgbdslam_ctx *ctx, int microseconds);
  * (or NULL): the NEXT rgbdslam_track_frame[_sharded] in persistent-loop mode reads them (one 16-byte gather instead of five
  * words from three maps, ~60 fewer issue slots per sample); they must belong to the maps passed to that call.  One call each. */
 int rgbdslam_set_frame_aux(rgbdslam_ctx *ctx, float *aux_write, const float *aux_read);
+/* The same records from maps that already exist (callers of the per-operator entry points): aux[n*m] f32x4, 16-byte aligned. */
+int rgbdslam_frame_aux(rgbdslam_ctx *ctx, const float *VMap, const float *RGB, const float *Gx, size_t gx_pitch, const float *Gy,
+                       size_t gy_pitch, float *aux, int n, int m);
 /* Stores up to RGBDSLAM_COPY_MAX_SEGMENTS device ranges into memory the device can write -- pinned host memory, or device
  * memory -- with ONE launch on the context's stream (no reference counterpart: the reference reads its poses back with blocking
  * cudaMemcpy, RG.cpp:898-903; a hipMemcpyAsync per range is a blit launch each).  Addresses and sizes are multiples of 4

@@ -158,6 +158,16 @@ class Context:
             C.c_size_t(pitch), _ptr(vprev), _ptr(nprev), _ptr(rgbd_prev), n, m, _ptr(pose_block), _ptr(history),
             int(frame_index)), "track_frame")
 
+    def frame_aux(self, vmap, rgb, gx, gy, aux, n, m, pitch=None):
+        """rgbdslam_frame_aux: the frame's auxiliary ICP records (f32 [n, m, 4]) from maps that already exist."""
+        pitch = pitch or 4 * m
+        _chk(self.lib.rgbdslam_frame_aux(self._h, _ptr(vmap), _ptr(rgb), _ptr(gx), C.c_size_t(pitch), _ptr(gy), C.c_size_t(pitch),
+                                         _ptr(aux), n, m), "frame_aux")
+
+    def set_frame_aux(self, aux_write=None, aux_read=None):
+        """rgbdslam_set_frame_aux: records the NEXT preprocessing launch writes / the NEXT track_frame reads (one call each)."""
+        _chk(self.lib.rgbdslam_set_frame_aux(self._h, _ptr(aux_write), _ptr(aux_read)), "set_frame_aux")
+
     def set_icp_loop(self, on):
         """Persistent-loop mode of track_frame (one launch per frame); raises when the device cannot hold the grid."""
         _chk(self.lib.rgbdslam_set_icp_loop(self._h, int(on)), "set_icp_loop")

@@ -271,3 +271,31 @@ extern "C" int rgbdslam_bilateral_depth(rgbdslam_ctx *ctx, uint16_t *dst, size_t
     HIP_TRY(hipGetLastError());
     return 0;
 }
+
+// ---- the frame's auxiliary ICP records from maps that already exist (no reference counterpart; rgbdslam_set_frame_aux) ----
+// For callers that preprocess with the per-operator entry points: the four values MatchKernelGaussNewton takes from a pixel of
+// the current frame (ICP.cu:167-173), by its own expressions on the stored maps.
+__global__ void k_frame_aux(const float *__restrict__ VMap, const float *__restrict__ RGB, const float *__restrict__ Gx, size_t gxp,
+                            const float *__restrict__ Gy, size_t gyp, float *__restrict__ aux, int n, int m) {
+    const int j = blockIdx.x * TILE_W + threadIdx.x, i = blockIdx.y * TILE_H + threadIdx.y;
+    if (i >= n || j >= m) return;
+    const size_t idx = (size_t)i * m + j;
+    const float gx = *(const float *)((const char *)Gx + (size_t)i * gxp + 4 * (size_t)j);
+    const float gy = *(const float *)((const char *)Gy + (size_t)i * gyp + 4 * (size_t)j);
+    float4 x;
+    x.x = (float)((double)gx / 8.0);
+    x.y = (float)((double)gy / 8.0);
+    x.z = ((RGB[3 * idx] + RGB[3 * idx + 1]) + RGB[3 * idx + 2]) / 3.0f;
+    x.w = icp_depth_weight(VMap[3 * idx + 2]);
+    *(float4 *)(aux + 4 * idx) = x;
+}
+
+extern "C" int rgbdslam_frame_aux(rgbdslam_ctx *ctx, const float *VMap, const float *RGB, const float *Gx, size_t gx_pitch,
+                                  const float *Gy, size_t gy_pitch, float *aux, int n, int m) {
+    if (!ctx || !VMap || !RGB || !Gx || !Gy || !aux || n <= 0 || m <= 0) return RGBDSLAM_E_ARG;
+    if (((uintptr_t)aux & 15) != 0 || gx_pitch < 4 * (size_t)m || gy_pitch < 4 * (size_t)m || ((gx_pitch | gy_pitch) & 3)) return RGBDSLAM_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    KLAUNCH(ctx, k_frame_aux, grid2d(n, m), block2d(), VMap, RGB, Gx, gx_pitch, Gy, gy_pitch, aux, n, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -123,7 +123,8 @@ class ShardedAligner:
     def _div_up(x, y):
         return (x + y - 1) // y if x % y else x // y
 
-    def align(self, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, pose_state, status, pitch=None):
+    def align(self, vmap, nmap, rgb, gx, gy, vprev, nprev, rgbd_prev, pose_state, status, pitch=None, aux=None):
+        """aux: the current frame's auxiliary ICP records (Context.frame_aux), used by the persistent form (peer_loop) only."""
         lib, h, prm, n, m = self.ctx.lib, self.ctx._h, self.prm, self.n, self.m
         pitch = pitch or 4 * m
         p = lambda t: C.c_void_p(t.data_ptr())
@@ -135,6 +136,8 @@ class ShardedAligner:
                 lo3[lvl], hi3[lvl] = band_rows(self.rank, self.world, self._div_up(n // (1 << lvl), 8))
                 if hi3[lvl] <= lo3[lvl]:
                     raise RuntimeError("peer exchange needs a non-empty band on every rank (level %d)" % lvl)
+            if aux is not None and lib.rgbdslam_set_frame_aux(h, None, p(aux)) != 0:
+                raise RuntimeError("set_frame_aux failed")
             rc = lib.rgbdslam_track_frame_sharded(h, C.byref(prm), p(vmap), p(nmap), p(rgb), p(gx), C.c_size_t(pitch), p(gy),
                                                   C.c_size_t(pitch), p(vprev), p(nprev), p(rgbd_prev), n, m, p(self.pb),
                                                   p(self.history), 0, lo3, hi3)

@@ -987,6 +987,9 @@ def test_frame_aux_records(ctx, pkg, orc, synth, shape):
             sd = (-rv[..., 2]).astype(np.float64)
             want[..., 3] = (0.0012 / (0.0012 + 0.0019 * (sd - 0.4) * (sd - 0.4))).astype(np.float32)
             same(host(aux), want)
+            alone = torch.full((n, m, 4), -7.0, device="cuda")          # the stand-alone form on the stored maps: the same records
+            ctx.frame_aux(v, rgb, gx, gy, alone, n, m)
+            same(host(alone), want)
             keep = aux.clone()
             aux.fill_(-7.0)
             assert call() == 0                                                      # (b) not announced again: nothing written
