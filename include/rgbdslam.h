@@ -51,7 +51,7 @@ int rgbdslam_set_sync_spin(rgbdslam_ctx *ctx, int microseconds);
  * 0.0019 (z' - 0.4)^2), z' = -VMap.z -- each the reference's expression on the frame's stored maps, so the sums are unchanged.
  * aux_write (16-byte aligned, n*m*16 bytes, or NULL): the NEXT launch that preprocesses a frame (rgbdslam_frame_preprocess,
  * ..._model_segment_merge_claim_preprocess, ..._update_apply_tracked_preprocess) leaves that frame's records there.  aux_read
- * (or NULL): the NEXT rgbdslam_track_frame[_sharded] in persistent-loop mode reads them (one 16-byte gather instead of five
+ * (or NULL): the NEXT rgbdslam_track_frame[_sharded], in either launch form, reads them (one 16-byte gather instead of five
  * words from three maps, ~60 fewer issue slots per sample); they must belong to the maps passed to that call.  One call each. */
 int rgbdslam_set_frame_aux(rgbdslam_ctx *ctx, float *aux_write, const float *aux_read);
 /* The same records from maps that already exist (callers of the per-operator entry points): aux[n*m] f32x4, 16-byte aligned. */

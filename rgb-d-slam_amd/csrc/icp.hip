@@ -1531,6 +1531,7 @@ struct IcpMaps {
     const float *VMap, *NMap, *RGB, *Gx, *Gy;
     size_t gxp, gyp;
     const float *VMap_prev, *NMap_prev, *RGB_prev;
+    const float *Aux;                                // the current frame's auxiliary records or NULL (rgbdslam_set_frame_aux)
 };
 
 // One launch of k_icp_iter over block rows [br_lo, br_hi) of the level's 8x8-block grid.
@@ -1593,7 +1594,8 @@ static int launch_iter(rgbdslam_ctx *ctx, const float *intr, const float *R, con
     a.line_check = ctx->icp_line_check; a.rejections = ctx->icp_epoch_dev ? ctx->icp_epoch_dev + ICP_OFF_REJECT_WORD : nullptr;
     a.timeout_ticks = ctx->icp_timeout_ticks;
     a.intr = intr; a.R = R; a.t = t;
-    a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp; a.Aux = nullptr;
+    a.VMap = mp.VMap; a.NMap = mp.NMap; a.RGB = mp.RGB; a.Gx = mp.Gx; a.Gy = mp.Gy; a.gxp = mp.gxp; a.gyp = mp.gyp;
+    a.Aux = (size_t)n * m * 16 <= 0xffffffffull ? mp.Aux : nullptr;
     a.VMap_prev = mp.VMap_prev; a.NMap_prev = mp.NMap_prev; a.RGBD_prev = mp.RGB_prev;
     a.distThres = icp_sq_threshold(distThres); a.angleThres = icp_sq_threshold(angleThres);
     a.n = n; a.m = m; a.fact = fact; a.grid_rows = gr; a.grid_cols = gc;
@@ -1663,7 +1665,7 @@ static int align_impl(rgbdslam_ctx *ctx, const rgbdslam_icp_params *prm, const f
     int rc = check_align_args(ctx, prm, n, m, gxp, gyp);
     if (rc) return rc;
     IcpState *st = ctx->icp_state;
-    IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev};
+    IcpMaps mp = {VMap, NMap, RGB, Gx, Gy, gxp, gyp, VMap_prev, NMap_prev, RGB_prev, aux};
     // track_frame: begin and end ride on the first and the last iteration launch
     const bool ride = pose_block != nullptr;
     IcpEndArgs end = {pose_state_dev, status_dev, pose_block, history, frame_index};

@@ -1003,7 +1003,8 @@ def test_frame_aux_records(ctx, pkg, orc, synth, shape):
         prm = pkg.icp_params()
         I = np.eye(3, dtype=np.float32).reshape(-1); z = np.zeros(3, np.float32)
         out = {}
-        for name, loop, use_aux in (("iter", False, False), ("loop", True, False), ("loop+aux", True, True), ("loop after", True, False)):
+        for name, loop, use_aux in (("iter", False, False), ("iter+aux", False, True), ("loop", True, False), ("loop+aux", True, True),
+                                    ("loop after", True, False)):
             ctx.set_icp_loop(loop)
             pb = _pose_block(torch, I, z)
             hist = torch.zeros(2, 16, device="cuda")
@@ -1016,7 +1017,7 @@ def test_frame_aux_records(ctx, pkg, orc, synth, shape):
             assert ctx.icp_loop_faults() == 0
             out[name] = host(pb).copy().view(np.int32)
         ctx.set_icp_loop(False)
-        for name in ("loop", "loop+aux", "loop after"):
+        for name in ("iter+aux", "loop", "loop+aux", "loop after"):
             same(out[name], out["iter"])
         ok, R, t, tr = orc.align_gauss_newton(orc.icp_params(), calib[:4], f1["hv"], f1["hn"], f1["hrgb"], f0["hv"], f0["hn"], rgbd0,
                                               I, z, I, z)
